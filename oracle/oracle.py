@@ -1,0 +1,227 @@
+"""ctypes front-end of the CPU parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; ``obia_amd`` (the product) never does.  See ``obia_oracle.c`` for what each
+function restates (reference file:line) and how it is pinned (scikit-image 0.18.3 golden vectors
+under ``tests/golden/``).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libobia_oracle.so")
+_lib = None
+
+_i64 = ctypes.c_int64
+_p = ctypes.c_void_p
+
+
+def build(force=False):
+    """Compile libobia_oracle.so with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "obia_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libobia_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.obia_oracle_grid_centroids.restype = _i64
+        _lib.obia_oracle_masked_grid_centroids.restype = _i64
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_p)
+
+
+def regular_grid(H, W, n_points):
+    """(start_y, step_y, start_x, step_x); step 0 == slice(None).  util/_regular_grid.py:61-83."""
+    out = np.zeros(4, np.int64)
+    lib().obia_oracle_regular_grid(_i64(H), _i64(W), _i64(n_points), _ptr(out))
+    return tuple(int(v) for v in out)
+
+
+def grid_centroids(H, W, n_segments):
+    steps = np.zeros(2, np.float64)
+    K = lib().obia_oracle_grid_centroids(_i64(H), _i64(W), _i64(n_segments), None, _ptr(steps))
+    yx = np.zeros((K, 2), np.int64)
+    lib().obia_oracle_grid_centroids(_i64(H), _i64(W), _i64(n_segments), _ptr(yx), _ptr(steps))
+    return yx, steps
+
+
+def masked_grid_centroids(mask, n_segments):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = mask.shape
+    steps = np.zeros(2, np.float64)
+    K = lib().obia_oracle_masked_grid_centroids(_ptr(mask), _i64(H), _i64(W), _i64(n_segments), None, _ptr(steps))
+    yx = np.zeros((K, 2), np.int64)
+    if K:
+        lib().obia_oracle_masked_grid_centroids(_ptr(mask), _i64(H), _i64(W), _i64(n_segments), _ptr(yx), _ptr(steps))
+    return yx, steps
+
+
+def normalize(img):
+    """obia normalize_band on every band (segment_boundaries.py:11-16,32-33); returns a copy."""
+    out = np.ascontiguousarray(img, np.float32).copy()
+    H, W, C = out.shape
+    lib().obia_oracle_normalize(_ptr(out), _i64(H * W), ctypes.c_int(C))
+    return out
+
+
+def rgb2lab(rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    out = np.empty_like(rgb)
+    lib().obia_oracle_rgb2lab_f32(_ptr(rgb), _ptr(out), _i64(rgb.shape[0] * rgb.shape[1]))
+    return out
+
+
+def slic_core(image_scaled, segments, step, max_iter=10, mask=None, slic_zero=False,
+              ignore_color=False, start_label=1):
+    """_slic_cython; `segments` (K,2+C) float32 is updated in place. Returns labels (H,W) int64."""
+    image_scaled = np.ascontiguousarray(image_scaled, np.float32)
+    H, W, C = image_scaled.shape
+    assert segments.dtype == np.float32 and segments.flags.c_contiguous and segments.shape[1] == 2 + C
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+    labels = np.empty((H, W), np.int64)
+    rc = lib().obia_oracle_slic_core(_ptr(image_scaled), _ptr(mask), _ptr(segments), _i64(H), _i64(W),
+                                     ctypes.c_int(C), _i64(segments.shape[0]), ctypes.c_float(step),
+                                     ctypes.c_int(max_iter), ctypes.c_int(bool(slic_zero)),
+                                     ctypes.c_int(bool(ignore_color)), ctypes.c_int(start_label), _ptr(labels))
+    if rc:
+        raise RuntimeError(f"oracle slic_core rc={rc}")
+    return labels
+
+
+def enforce_connectivity(labels, min_size, max_size, start_label=1):
+    labels = np.ascontiguousarray(labels, np.int64)
+    H, W = labels.shape
+    out = np.empty_like(labels)
+    rc = lib().obia_oracle_enforce_connectivity(_ptr(labels), _i64(H), _i64(W), _i64(min_size), _i64(max_size),
+                                                ctypes.c_int(start_label), _ptr(out))
+    if rc:
+        raise RuntimeError(f"oracle enforce_connectivity rc={rc}")
+    return out
+
+
+def slic(image, n_segments=100, compactness=10.0, max_iter=10, convert2lab=None,
+         enforce_connectivity=True, min_size_factor=0.5, max_size_factor=3, slic_zero=False,
+         start_label=1, mask=None, seeds_yx=None, seed_steps=None, return_all=False):
+    """skimage.segmentation.slic for a (H,W,C) float32 image (slic_superpixels.py:107-333).
+
+    With ``mask`` and no ``seeds_yx`` the build's masked-grid seeding rule is used (see
+    obia_oracle.c); with ``seeds_yx`` (K,2 float64) + ``seed_steps`` the given seeds are used,
+    which is how the maskSLIC path is pinned on scikit-image's own seeds.
+    """
+    image = np.ascontiguousarray(image, np.float32)
+    if image.ndim == 2:
+        image = image[..., None]
+    H, W, C = image.shape
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+    c2l = -1 if convert2lab is None else int(bool(convert2lab))
+    labels = np.empty((H, W), np.int64)
+    pre = np.empty((H, W), np.int64)
+    if seeds_yx is not None:
+        seeds_yx = np.ascontiguousarray(seeds_yx, np.float64)
+        seed_steps = np.ascontiguousarray(seed_steps, np.float64)
+        kmax = seeds_yx.shape[0]
+    else:
+        kmax = H * W
+        if mask is None:
+            kmax = grid_centroids(H, W, n_segments)[0].shape[0]
+        else:
+            kmax = max(1, masked_grid_centroids(mask, n_segments)[0].shape[0])
+    cent = np.zeros((kmax, 2 + C), np.float32)
+    K = _i64(0)
+    rc = lib().obia_oracle_slic(_ptr(image), _ptr(mask), _i64(H), _i64(W), ctypes.c_int(C), _i64(n_segments),
+                                ctypes.c_double(compactness), ctypes.c_int(max_iter), ctypes.c_int(c2l),
+                                ctypes.c_int(bool(enforce_connectivity)), ctypes.c_double(min_size_factor),
+                                ctypes.c_double(max_size_factor), ctypes.c_int(bool(slic_zero)),
+                                ctypes.c_int(start_label), _ptr(seeds_yx),
+                                _i64(0 if seeds_yx is None else seeds_yx.shape[0]), _ptr(seed_steps),
+                                _ptr(labels), _ptr(pre), _ptr(cent), ctypes.byref(K))
+    if rc:
+        raise ValueError(f"oracle slic rc={rc}")
+    if return_all:
+        return labels, pre, cent[:K.value]
+    return labels
+
+
+def zonal_stats_numpy(raw, labels, bands=None, start_label=1, n_labels=None):
+    """Bit-faithful restatement of calculate_spectral_stats (segment_statistics.py:143-172) under
+    the equivalence of SURVEY.md 3.3: np.mean / np.var / np.min / np.max over the float32 pixels
+    of each label.  Returns dict of arrays (n_labels, n_bands); NaN for empty labels."""
+    raw = np.asarray(raw)
+    H, W, C = raw.shape
+    if bands is None:
+        bands = list(range(C))
+    lab = np.asarray(labels).ravel()
+    if n_labels is None:
+        n_labels = int(lab.max()) - start_label + 1 if lab.size else 0
+    order = np.argsort(lab, kind="stable")
+    sl = lab[order]
+    out = {k: np.full((n_labels, len(bands)), np.nan, np.float64) for k in ("mean", "variance", "min", "max")}
+    cnt = np.zeros(n_labels, np.int64)
+    flat = raw.reshape(-1, C)
+    lo = np.searchsorted(sl, np.arange(start_label, start_label + n_labels), "left")
+    hi = np.searchsorted(sl, np.arange(start_label, start_label + n_labels), "right")
+    for i in range(n_labels):
+        idx = order[lo[i]:hi[i]]
+        cnt[i] = idx.size
+        if idx.size == 0:
+            continue
+        for j, b in enumerate(bands):
+            v = flat[idx, b]
+            v = v[~np.isnan(v)]
+            if v.size == 0:
+                continue
+            out["mean"][i, j] = np.mean(v)
+            out["variance"][i, j] = np.var(v)
+            out["min"][i, j] = np.min(v)
+            out["max"][i, j] = np.max(v)
+    out["count"] = cnt
+    return out
+
+
+def zonal_stats_c(raw, labels, bands=None, start_label=1, n_labels=None):
+    """float64-accumulating C port (timing baseline; obia_oracle_zonal_stats)."""
+    raw = np.ascontiguousarray(raw, np.float32)
+    H, W, C = raw.shape
+    labels = np.ascontiguousarray(labels, np.int64)
+    if bands is None:
+        bands = list(range(C))
+    b = np.ascontiguousarray(bands, np.int32)
+    if n_labels is None:
+        n_labels = int(labels.max()) - start_label + 1
+    cnt = np.zeros(n_labels, np.int64)
+    mean = np.zeros((n_labels, len(b)), np.float64)
+    var = np.zeros_like(mean)
+    mn = np.zeros((n_labels, len(b)), np.float32)
+    mx = np.zeros_like(mn)
+    rc = lib().obia_oracle_zonal_stats(_ptr(raw), _ptr(labels), _i64(H * W), ctypes.c_int(C), _ptr(b),
+                                       ctypes.c_int(len(b)), _i64(n_labels), ctypes.c_int(start_label),
+                                       _ptr(cnt), _ptr(mean), _ptr(var), _ptr(mn), _ptr(mx))
+    if rc:
+        raise RuntimeError(f"oracle zonal rc={rc}")
+    return {"count": cnt, "mean": mean, "variance": var, "min": mn, "max": mx}
+
+
+def quickshift_core(image_f64, noise, kernel_size, max_dist):
+    image_f64 = np.ascontiguousarray(image_f64, np.float64)
+    noise = np.ascontiguousarray(noise, np.float64)
+    H, W, C = image_f64.shape
+    out = np.empty((H, W), np.int64)
+    rc = lib().obia_oracle_quickshift_core(_ptr(image_f64), _ptr(noise), _i64(H), _i64(W), ctypes.c_int(C),
+                                           ctypes.c_double(kernel_size), ctypes.c_double(max_dist), _ptr(out))
+    if rc:
+        raise RuntimeError(f"oracle quickshift rc={rc}")
+    return out
