@@ -1,0 +1,314 @@
+// cc.hip -- connectivity enforcement of a SLIC label map on gfx950.
+//
+// Restates _enforce_label_connectivity_cython (scikit-image _slic.pyx, called from
+// slic_superpixels.py:320-328; oracle/obia_oracle.c: obia_oracle_enforce_connectivity).  The reference
+// is a raster-order sequential BFS.  What is order-INDEPENDENT in it is reproduced exactly:
+//   * components are the 4-connected regions of equal label (masked pixels excluded);
+//   * a component keeps its own label iff size >= min_size, and surviving components are numbered
+//     consecutively from start_label in raster order of their FIRST pixel
+//     (union-find by minimum pixel index -> the root IS the first pixel; ranks by a prefix sum);
+//   * a component smaller than min_size takes the label of `adjacent`: the LAST neighbour pixel, in
+//     the BFS order of the reference (neighbour order x+1, x-1, y+1, y-1), that already carries a
+//     label -- i.e. belongs to a component whose first pixel precedes this BFS's start pixel.  Small
+//     components are rare and small, so one lane replays the BFS of each of them exactly; chains
+//     small -> small -> ... -> survivor are resolved afterwards.
+// Deliberately NOT reproduced (DESIGN.md "connectivity"): the split of components that reach max_size
+// (the BFS of the reference stops there and the rest is re-seeded, an order-dependent cut that no
+// BASELINE configuration triggers), and the exact bookkeeping of small components that find no
+// labelled neighbour on their first BFS and are re-seeded from a later pixel (replayed here with the
+// same start pixels, but neighbours are classified by root order only).
+#include "slic.hpp"
+
+namespace obia {
+
+__device__ __forceinline__ int ld_agent(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int find_root(const int *parent, int i) {
+    int p;
+    while ((p = ld_agent(&parent[i])) != i) i = p;
+    return i;
+}
+
+// link the larger root under the smaller one; lock-free (Komura / Playne-Hawick style)
+__device__ __forceinline__ void unite(int *parent, int a, int b) {
+    for (;;) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_init_kernel(const int32_t *__restrict__ lab, int *__restrict__ parent,
+                                                      int *__restrict__ size, int H, int W, int mask_label) {
+    const long long n = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int l = lab[i];
+        int p = (int)i;
+        // start every pixel at the head of its horizontal run where that is one step away
+        if (l == mask_label) p = -1;
+        else if ((int)(i % W) > 0 && lab[i - 1] == l) p = (int)i - 1;
+        parent[i] = p;
+        size[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_union_kernel(const int32_t *__restrict__ lab, int *__restrict__ parent,
+                                                       int H, int W, int mask_label) {
+    const long long n = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int l = lab[i];
+        if (l == mask_label) continue;
+        const int y = (int)(i / W);
+        if (y > 0 && lab[i - W] == l) {
+            // only the first pixel of a horizontal contact needs to issue the union
+            const int x = (int)(i % W);
+            const bool left_same = x > 0 && lab[i - 1] == l && lab[i - W - 1] == l;
+            if (!left_same) unite(parent, (int)i, (int)(i - W));
+        }
+    }
+}
+
+// flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n) {
+    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < n; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+        int r = -1;
+        if (i < n && parent[i] >= 0) r = find_root(parent, (int)i);
+        bool todo = r >= 0;
+        while (true) {
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const int rr = __shfl(r, leader);
+            const unsigned long long same = __ballot(todo && r == rr);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[rr], (int)__popcll(same));
+            if (r == rr) todo = false;
+        }
+        if (i < n && r >= 0) parent[i] = r;   // roots only move to smaller indices, final value is the root
+    }
+}
+
+constexpr int SCAN_NT = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_NT * SCAN_PER;
+
+// flag(i) = pixel i is the root of a surviving component
+__device__ __forceinline__ int survivor_flag(const int *parent, const int *size, long long i, int min_size) {
+    return (parent[i] == (int)i && size[i] >= min_size) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const int *__restrict__ parent, const int *__restrict__ size,
+                                                                   long long n, int min_size, int *__restrict__ block_sums,
+                                                                   int *__restrict__ counters /*[0]=n_small [1]=small_px*/) {
+    __shared__ int s_w[SCAN_NT / 64];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    int c = 0, nsmall = 0, spx = 0;
+    for (int j = 0; j < SCAN_PER; ++j) {
+        const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
+        if (i < n && parent[i] == (int)i) {
+            const int sz = size[i];
+            if (sz >= min_size) c += 1;
+            else { nsmall += 1; spx += sz; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); nsmall += __shfl_xor(nsmall, off); spx += __shfl_xor(spx, off); }
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = c;
+        if (nsmall) { atomicAdd(&counters[0], nsmall); atomicAdd(&counters[1], spx); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of block_sums in place, single workgroup; total -> counters[2]
+__global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ block_sums, int nb, int *__restrict__ counters) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, nb);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_sums[i];
+    s_part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - s;
+    for (int i = lo; i < hi; ++i) { const int v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (tid == 1023) counters[2] = s_part[1023];
+}
+
+// newlab[root] = rank (>= 0) for survivors, -(index+2) for small components (collected in small_list)
+__global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const int *__restrict__ parent, const int *__restrict__ size,
+                                                                long long n, int min_size, const int *__restrict__ block_sums,
+                                                                int *__restrict__ newlab, int *__restrict__ small_list,
+                                                                int *__restrict__ small_qoff, int *__restrict__ counters /*[3]=list cursor [4]=queue cursor*/) {
+    __shared__ int s_w[SCAN_NT / 64];
+    __shared__ int s_run;
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = block_sums[blockIdx.x];
+    __syncthreads();
+    for (int j = 0; j < SCAN_PER; ++j) {
+        const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
+        int flag = 0;
+        bool small = false;
+        int sz = 0;
+        if (i < n && parent[i] == (int)i) {
+            sz = size[i];
+            flag = sz >= min_size;
+            small = !flag;
+        }
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) s_w[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += s_w[w];
+        const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (flag) newlab[i] = s_run + before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (small) {
+            const int idx = atomicAdd(&counters[3], 1);
+            small_list[idx] = (int)i;
+            small_qoff[idx] = atomicAdd(&counters[4], sz);
+            newlab[i] = -(idx + 2);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += total;
+        __syncthreads();
+    }
+}
+
+// BFS of the reference over the component rooted at r, started at `start`; neighbour order
+// (x+1, x-1, y+1, y-1).  A neighbour of another component counts as "already labelled" when that
+// component's first pixel precedes `start` in raster order.  Returns the last such neighbour met.
+__device__ int replay_bfs(const int *__restrict__ parent, int r, int start, int mark, int H, int W,
+                          int *__restrict__ q, int32_t *__restrict__ out, int *n_out) {
+    int head = 0, tail = 1, adjacent = -1;
+    q[0] = start;
+    out[start] = mark;
+    while (head < tail) {
+        const int p = q[head++];
+        const int y = p / W, x = p - y * W;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
+            const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const int nb = yy * W + xx;
+            const int rn = parent[nb];
+            if (rn == r) {
+                if (out[nb] != mark) { out[nb] = mark; q[tail++] = nb; }
+            } else if (rn >= 0 && rn < start) {
+                adjacent = nb;     // the LAST labelled neighbour met wins
+            }
+        }
+    }
+    *n_out = tail;
+    return adjacent;
+}
+
+// One lane replays the reference BFS of one small component.  `out` doubles as the visited map
+// (it is rewritten by the final relabel pass).  target[s] = adjacent pixel, or -1.
+__global__ __launch_bounds__(64) void cc_small_bfs_kernel(const int *__restrict__ parent,
+                                                          const int *__restrict__ small_list, const int *__restrict__ small_qoff,
+                                                          int n_small, int H, int W, int start_label,
+                                                          int *__restrict__ queue, int32_t *__restrict__ out,
+                                                          int *__restrict__ target) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_small) return;
+    const int r = small_list[s];
+    int *q = queue + small_qoff[s];
+    int csize = 0;
+    int adjacent = replay_bfs(parent, r, r, -(s + 2), H, W, q, out, &csize);
+    if (adjacent < 0 && start_label == 1) {
+        // `adjacent = 0` means "unset" when start_label is 1: the reference meets the component again at
+        // its next pixel in raster order and replays the BFS from there (rare: no earlier neighbour).
+        for (int a = 1; a < csize && adjacent < 0; ++a) {
+            for (int i = 1; i < csize; ++i) {   // insertion sort: raster order of the component's pixels
+                const int v = q[i];
+                int j = i - 1;
+                while (j >= 0 && q[j] > v) { q[j + 1] = q[j]; --j; }
+                q[j + 1] = v;
+            }
+            const int start = q[a];
+            for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the last attempt
+            int n2 = 0;
+            adjacent = replay_bfs(parent, r, start, -(s + 2), H, W, q, out, &n2);
+        }
+    }
+    target[s] = adjacent;
+}
+
+// final labels: survivors get rank + start_label; small components follow their adjacency chain
+__global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__ parent, const int *__restrict__ newlab,
+                                                         const int *__restrict__ target, long long n, int start_label,
+                                                         int mask_label, int32_t *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = parent[i];
+        int res;
+        if (r < 0) res = mask_label;
+        else {
+            int nl = newlab[r];
+            int hops = 0;
+            while (nl < 0) {
+                const int t = target[-nl - 2];
+                if (t < 0 || ++hops > 64) { nl = -1; break; }
+                nl = newlab[parent[t]];
+            }
+            res = (nl >= 0) ? nl + start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
+        }
+        out[i] = res;
+    }
+}
+
+int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size, int max_size,
+                             int start_label, int32_t *labels_out, int *h_n_labels_out) {
+    (void)max_size;
+    ScopedSpan span(ctx, T_CC);
+    Arena &A = ctx->arena;
+    const long long n = (long long)H * W;
+    if (n <= 0 || n > 0x7fffffffLL) { set_error("label map of %lld pixels not supported", n); return OBIA_E_INVALID; }
+    const int mask_label = start_label - 1;
+    int *parent = A.get<int>(n), *size = A.get<int>(n), *newlab = A.get<int>(n);
+    const int nb = cdiv(n, SCAN_CHUNK);
+    int *block_sums = A.get<int>(nb);
+    int *counters = A.get<int>(8);
+    if (!parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+    int gs = cdiv(n, 256 * 4);
+    if (gs > 65535 * 4) gs = 65535 * 4;
+    hipLaunchKernelGGL(cc_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_in, parent, size, H, W, mask_label);
+    hipLaunchKernelGGL(cc_union_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_in, parent, H, W, mask_label);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n);
+    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, parent, size, n, min_size, block_sums, counters);
+    hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
+    int hc[8];
+    OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));
+    const int n_small = hc[0], small_px = hc[1], n_surv = hc[2];
+    int *small_list = A.get<int>(n_small > 0 ? n_small : 1);
+    int *small_qoff = A.get<int>(n_small > 0 ? n_small : 1);
+    int *target = A.get<int>(n_small > 0 ? n_small : 1);
+    int *queue = A.get<int>(small_px > 0 ? small_px : 1);
+    if (!small_list || !small_qoff || !target || !queue) return OBIA_E_NOMEM;
+    hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, parent, size, n, min_size, block_sums,
+                       newlab, small_list, small_qoff, counters);
+    if (n_small > 0) {
+        OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
+        hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, parent, small_list,
+                           small_qoff, n_small, H, W, start_label, queue, labels_out, target);
+    }
+    hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
+                       mask_label, labels_out);
+    OBIA_HIP_TRY(hipGetLastError());
+    if (h_n_labels_out) *h_n_labels_out = n_surv;
+    return OBIA_OK;
+}
+
+}  // namespace obia

@@ -1,0 +1,846 @@
+// slic.hip -- batched SLIC engine for gfx950: feature preparation, seeding, centroid binning and the
+// pixel-centric assign + fused-accumulate sweep.
+//
+// What it restates (all third-party arithmetic reached from obia/segmentation/segment_boundaries.py:48-51):
+//   normalize_band                     segment_boundaries.py:11-16,32-33
+//   slic() driver                      skimage slic_superpixels.py:107-333
+//   _slic_cython assign/update loop    skimage _slic.pyx (0.18.3), see oracle/obia_oracle.c
+// The reference loop is segment-centric (each centroid scatters into its (4S+1)^2 window, ties to the
+// lowest k).  Here it is pixel-centric: centroids are binned by their CURRENT position every sweep, a
+// workgroup owning a 32x32 pixel tile stages into LDS exactly the centroids whose window intersects
+// the tile, and every lane takes the lexicographic minimum of (distance, k) over the candidates whose
+// window contains its pixel -- the same candidate set and the same tie rule.  Distances use the
+// reference's operation order in float32 with contraction off, so they are bit-equal to the x86
+// build.  The centroid update is fused into the sweep: per-lane run sums -> LDS partials -> one
+// global integer atomic per (tile, centroid, field); colour sums are 64-bit fixed point, so the sums
+// (and therefore the whole segmentation) do not depend on the order of the atomics.
+#include "slic.hpp"
+
+#include <cmath>
+
+namespace obia {
+
+// ------------------------------------------------------------------------------------------------
+// host: regular_grid((1,H,W), n)  -- skimage/util/_regular_grid.py:61-83
+// ------------------------------------------------------------------------------------------------
+void regular_grid_hw(long long H, long long W, long long n, long long out[4]) {
+    long long dims[3] = {1, H, W};
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (dims[order[j]] < dims[order[i]]) std::swap(order[i], order[j]);
+    double sd[3];
+    for (int i = 0; i < 3; ++i) sd[i] = (double)dims[order[i]];
+    double space = sd[0] * sd[1] * sd[2];
+    if (space <= (double)n) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    double st[3];
+    for (int i = 0; i < 3; ++i) st[i] = std::pow(space / (double)n, 1.0 / 3.0);
+    auto all_ge = [&]() { return sd[0] >= st[0] && sd[1] >= st[1] && sd[2] >= st[2]; };
+    if (!all_ge()) {
+        for (int d = 0; d < 3; ++d) {
+            st[d] = sd[d];
+            double sp = 1.0;
+            for (int e = d + 1; e < 3; ++e) sp *= sd[e];
+            if (d < 2) {
+                double v = std::pow(sp / (double)n, 1.0 / (double)(3 - d - 1));
+                for (int e = d + 1; e < 3; ++e) st[e] = v;
+            }
+            if (all_ge()) break;
+        }
+    }
+    long long start[3], step[3], s_of[3], t_of[3];
+    for (int i = 0; i < 3; ++i) {
+        start[i] = (long long)std::floor(st[i] / 2.0);
+        step[i] = (long long)std::nearbyint(st[i]);   // np.round: half to even
+    }
+    for (int i = 0; i < 3; ++i) { s_of[order[i]] = start[i]; t_of[order[i]] = step[i]; }
+    out[0] = s_of[1]; out[1] = t_of[1]; out[2] = s_of[2]; out[3] = t_of[2];
+}
+
+static long long slice_len(long long L, long long start, long long step) {
+    if (step == 0) return L;
+    if (start >= L) return 0;
+    return (L - start + step - 1) / step;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2key(float f) {   // order-preserving float -> uint
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+constexpr int FP_NT = 256;
+
+// K0a: per-band min/max of each problem window.  Threads own a fixed band (stride is a multiple of
+// C), elements of a row are read as coalesced dwords.  grid = (blocks, nprob).
+__global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restrict__ src, int Ws, int C,
+                                                            const SrcWindow *__restrict__ wins,
+                                                            unsigned *__restrict__ keys /*[nprob][C][2]*/,
+                                                            int *__restrict__ nonfinite) {
+    __shared__ unsigned s_mn[32], s_mx[32];
+    const int p = blockIdx.y;
+    const SrcWindow wdw = wins[p];
+    const int active = (FP_NT / C) * C;
+    const int tid = threadIdx.x;
+    if (tid < 32) { s_mn[tid] = 0xffffffffu; s_mx[tid] = 0u; }
+    __syncthreads();
+    float lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
+    if (tid < active) {
+        const long long row_elems = (long long)wdw.w * C;
+        for (int y = blockIdx.x; y < wdw.h; y += gridDim.x) {
+            const float *row = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0) * C;
+            for (long long e = tid; e < row_elems; e += active) {
+                float v = row[e];
+                bad |= !(fabsf(v) <= 3.4028234e38f);
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
+        }
+        const int band = tid % C;
+        if (lo <= hi) {
+            atomicMin(&s_mn[band], f2key(lo));
+            atomicMax(&s_mx[band], f2key(hi));
+        }
+        if (bad) atomicOr(nonfinite, 1);
+    }
+    __syncthreads();
+    if (tid < C) {
+        if (s_mn[tid] != 0xffffffffu) atomicMin(&keys[((long long)p * C + tid) * 2 + 0], s_mn[tid]);
+        if (s_mx[tid] != 0u) atomicMax(&keys[((long long)p * C + tid) * 2 + 1], s_mx[tid]);
+    }
+}
+
+// skimage.color.rgb2lab on float32 (colorconv.py rgb2xyz + xyz2lab, D65 / 2 degree observer).
+__device__ __forceinline__ void rgb2lab_f32(float r, float g, float b, float &L, float &A, float &B) {
+    float a[3] = {r, g, b};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = a[c];
+        a[c] = (v > 0.04045f) ? powf((v + 0.055f) / 1.055f, 2.4f) : v / 12.92f;
+    }
+    const float m[3][3] = {{0.412453f, 0.357580f, 0.180423f},
+                           {0.212671f, 0.715160f, 0.072169f},
+                           {0.019334f, 0.119193f, 0.950227f}};
+    const float wr[3] = {0.95047f, 1.0f, 1.08883f};
+    float xyz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float s = a[0] * m[i][0];
+        s = s + a[1] * m[i][1];
+        s = s + a[2] * m[i][2];
+        s = s / wr[i];
+        xyz[i] = (s > 0.008856f) ? cbrtf(s) : 7.787f * s + 16.0f / 116.0f;
+    }
+    L = 116.0f * xyz[1] - 16.0f;
+    A = 500.0f * (xyz[0] - xyz[1]);
+    B = 200.0f * (xyz[1] - xyz[2]);
+}
+
+// K0b: features = [normalize_band] -> [rgb2lab] -> * float32(1/compactness), written to the dense
+// per-problem buffer padded to CP channels (padding is 0: `t = 0 - 0; dc += t*t` leaves every
+// distance bit-identical).  Also reduces max|feature| for the fixed-point scale.
+template <int CP>
+__global__ __launch_bounds__(256) void features_kernel(const float *__restrict__ src, int Ws, int C,
+                                                       const SrcWindow *__restrict__ wins,
+                                                       const unsigned *__restrict__ keys, int normalize,
+                                                       int to_lab, float ratio, float *__restrict__ feat,
+                                                       unsigned *__restrict__ maxabs_bits) {
+    const int p = blockIdx.y;
+    const SrcWindow wdw = wins[p];
+    const long long npix = (long long)wdw.h * wdw.w;
+    float local_max = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / wdw.w), x = (int)(i % wdw.w);
+        const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
+        float v[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            float t = 0.0f;
+            if (c < C) {
+                t = px[c];
+                if (normalize) {
+                    const float mn = key2f(keys[((long long)p * C + c) * 2 + 0]);
+                    const float mx = key2f(keys[((long long)p * C + c) * 2 + 1]);
+                    t = (t - mn) / (mx - mn);
+                }
+            }
+            v[c] = t;
+        }
+        if (to_lab) {
+            float L, A, B;
+            rgb2lab_f32(v[0], v[1], v[2], L, A, B);
+            v[0] = L; v[1] = A; v[2] = B;
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            v[c] = v[c] * ratio;
+            local_max = fmaxf(local_max, fabsf(v[c]));
+        }
+        float4 *dst = reinterpret_cast<float4 *>(feat + (wdw.pix_off + i) * CP);
+#pragma unroll
+        for (int q = 0; q < CP / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    // wave max -> one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxabs_bits, __float_as_uint(local_max));
+}
+
+
+int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
+                          int to_lab, float ratio) {
+    (void)Hs;
+    ScopedSpan span(ctx, T_FEAT);
+    const int C = b.C;
+    if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
+    unsigned *d_keys = ctx->arena.get<unsigned>((size_t)b.nprob * C * 2 + 2);
+    if (!d_keys) return OBIA_E_NOMEM;
+    unsigned *d_flags = d_keys + (size_t)b.nprob * C * 2;   // [0] nonfinite flag, [1] max|feature| bits
+    {
+        std::vector<unsigned> init((size_t)b.nprob * C * 2 + 2);
+        for (size_t i = 0; i < (size_t)b.nprob * C; ++i) { init[2 * i] = 0xffffffffu; init[2 * i + 1] = 0u; }
+        init[(size_t)b.nprob * C * 2] = 0; init[(size_t)b.nprob * C * 2 + 1] = 0;
+        OBIA_HIP_TRY(hipMemcpyAsync(d_keys, init.data(), init.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `init` is pageable host memory
+    }
+    int maxh = 1;
+    long long maxpix = 1;
+    for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; long long n = (long long)w.h * w.w; if (n > maxpix) maxpix = n; }
+    if (normalize) {
+        dim3 grid(maxh < 2048 ? maxh : 2048, b.nprob);
+        hipLaunchKernelGGL(band_minmax_kernel, grid, dim3(FP_NT), 0, ctx->stream, src, Ws, C, b.d_windows, d_keys,
+                           (int *)d_flags);
+    }
+    {
+        int blocks = cdiv(maxpix, 256);
+        if (blocks > 8192) blocks = 8192;
+        dim3 grid(blocks, b.nprob);
+#define LAUNCH_FEAT(CPV)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, ctx->stream, src, Ws, C,    \
+                       b.d_windows, d_keys, normalize, to_lab, ratio, b.d_feat, d_flags + 1)
+        switch (b.CP) {
+            case 4: LAUNCH_FEAT(4); break;
+            case 8: LAUNCH_FEAT(8); break;
+            case 12: LAUNCH_FEAT(12); break;
+            case 16: LAUNCH_FEAT(16); break;
+            default: set_error("bad CP %d", b.CP); return OBIA_E_INVALID;
+        }
+#undef LAUNCH_FEAT
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    // one read-back: min/max keys (constant-band check), non-finite flag, max|feature|
+    std::vector<unsigned> host((size_t)b.nprob * C * 2 + 2);
+    OBIA_TRY(read_back(ctx, host.data(), d_keys, host.size() * sizeof(unsigned)));
+    auto k2f = [](unsigned k) { unsigned bb = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &bb, 4); return f; };
+    if (normalize) {
+        if (host[(size_t)b.nprob * C * 2]) { set_error("input raster holds NaN or infinite values"); return OBIA_E_NONFINITE; }
+        for (int p = 0; p < b.nprob; ++p)
+            for (int c = 0; c < C; ++c) {
+                float mn = k2f(host[((size_t)p * C + c) * 2]), mx = k2f(host[((size_t)p * C + c) * 2 + 1]);
+                if (!(mx > mn)) {
+                    set_error("band %d is constant (%g) in window %d: normalize_band would divide 0 by 0 "
+                              "(obia/segmentation/segment_boundaries.py:16)", c, (double)mn, p);
+                    return OBIA_E_NONFINITE;
+                }
+            }
+    }
+    float maxabs; unsigned mb = host[(size_t)b.nprob * C * 2 + 1]; memcpy(&maxabs, &mb, 4);
+    if (!(maxabs <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
+    // fixed-point scale for the colour sums: |feature| * maxcount * 2^s < 2^62
+    long long maxcount = 1;
+    for (auto &w : b.windows) { long long n = (long long)w.h * w.w; if (n > maxcount) maxcount = n; }
+    double bound = ((double)maxabs + 1e-30) * (double)maxcount;
+    int s = 62 - (int)std::ceil(std::log2(bound + 1.0));
+    if (s > 40) s = 40;
+    if (s < -60) s = -60;
+    b.fscale = std::ldexp(1.0, s);
+    return OBIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// seeding
+// ------------------------------------------------------------------------------------------------
+struct SeedGrid { int start_y, step_y, ny, start_x, step_x, nx; int cent_off; int pad; };
+
+// unmasked: centroid k of problem p sits on the regular grid (slic_superpixels.py:71-104)
+__global__ void seed_grid_kernel(const SeedGrid *__restrict__ grids, int nprob, float *__restrict__ seed,
+                                 int *__restrict__ cent_prob) {
+    const int p = blockIdx.y;
+    const SeedGrid g = grids[p];
+    const int K = g.ny * g.nx;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int iy = k / g.nx, ix = k % g.nx;
+        seed[2 * (size_t)(g.cent_off + k)] = (float)(g.start_y + iy * g.step_y);
+        seed[2 * (size_t)(g.cent_off + k) + 1] = (float)(g.start_x + ix * g.step_x);
+        cent_prob[g.cent_off + k] = p;
+    }
+}
+
+// masked: keep the grid points that fall on valid pixels, in row-major order (DESIGN.md "masked-grid
+// seeding"); if none does, seed the first valid pixel.  One workgroup per problem.
+__global__ __launch_bounds__(256) void seed_masked_kernel(const SeedGrid *__restrict__ grids,
+                                                          const SlicProblem *__restrict__ probs,
+                                                          const uint8_t *__restrict__ mask, float *__restrict__ seed,
+                                                          int *__restrict__ cent_prob, int *__restrict__ K_out) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    __shared__ unsigned long long s_first;
+    const int p = blockIdx.x;
+    const SeedGrid g = grids[p];
+    const SlicProblem P = probs[p];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_base = 0; s_first = ~0ull; }
+    __syncthreads();
+    const int Kg = g.ny * g.nx;
+    for (int k0 = 0; k0 < Kg; k0 += 256) {
+        const int k = k0 + tid;
+        int y = 0, x = 0;
+        bool keep = false;
+        if (k < Kg) {
+            y = g.start_y + (k / g.nx) * g.step_y;
+            x = g.start_x + (k % g.nx) * g.step_x;
+            keep = mask[P.pix_off + (long long)y * P.W + x] != 0;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += s_wave[w];
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const int rank = s_base + before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
+            seed[2 * (size_t)(g.cent_off + rank)] = (float)y;
+            seed[2 * (size_t)(g.cent_off + rank) + 1] = (float)x;
+            cent_prob[g.cent_off + rank] = p;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    int K = s_base;
+    if (K == 0) {
+        const long long npix = (long long)P.H * P.W;
+        unsigned long long best = ~0ull;
+        for (long long i = tid; i < npix; i += 256)
+            if (mask[P.pix_off + i]) { best = (unsigned long long)i; break; }
+        atomicMin(&s_first, best);
+        __syncthreads();
+        if (tid == 0 && s_first != ~0ull) {
+            seed[2 * (size_t)g.cent_off] = (float)(s_first / P.W);
+            seed[2 * (size_t)g.cent_off + 1] = (float)(s_first % P.W);
+            cent_prob[g.cent_off] = p;
+        }
+        K = (s_first != ~0ull) ? 1 : 0;
+    }
+    if (tid == 0) K_out[p] = K;
+}
+
+// valid-pixel count per problem (mask.sum(), tiling.py:133 / slic_superpixels.py:322)
+__global__ __launch_bounds__(256) void count_valid_kernel(const SlicProblem *__restrict__ probs,
+                                                          const uint8_t *__restrict__ mask, int *__restrict__ out) {
+    const int p = blockIdx.y;
+    const SlicProblem P = probs[p];
+    const long long npix = (long long)P.H * P.W;
+    int c = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x)
+        c += mask[P.pix_off + i] != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&out[p], c);
+}
+
+__global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+constexpr int TW = 32, TH = 32, NT = 256, PPT = 4;   // tile, threads, pixels per thread
+constexpr int MAXC = 128;                            // LDS candidate slots per round
+constexpr int REC = 8;                               // header dwords of a centroid record
+
+int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments) {
+    const int np = b.nprob;
+    Arena &A = ctx->arena;
+    // problems carry H, W, pix_off already (set by the caller); upload a first version for the
+    // counting / seeding kernels
+    b.d_probs = A.get<SlicProblem>(np);
+    if (!b.d_probs) return OBIA_E_NOMEM;
+    std::vector<int> nvalid(np);
+    if (b.masked) {
+        OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+        int *d_cnt = A.get<int>(np);
+        if (!d_cnt) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * np, ctx->stream));
+        long long maxpix = 1;
+        for (auto &P : b.probs) { long long n = (long long)P.H * P.W; if (n > maxpix) maxpix = n; }
+        int blocks = cdiv(maxpix, 256 * 16);
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(count_valid_kernel, dim3(blocks, np), dim3(256), 0, ctx->stream, b.d_probs, b.d_mask, d_cnt);
+        OBIA_TRY(read_back(ctx, nvalid.data(), d_cnt, sizeof(int) * np));
+    } else {
+        for (int p = 0; p < np; ++p) nvalid[p] = b.probs[p].H * b.probs[p].W;
+    }
+    std::vector<SeedGrid> grids(np);
+    std::vector<double> stepmax(np);
+    int cent_off = 0;
+    for (int p = 0; p < np; ++p) {
+        SlicProblem &P = b.probs[p];
+        P.n_valid = nvalid[p];
+        SeedGrid &g = grids[p];
+        g.cent_off = cent_off; g.pad = 0;
+        if (nvalid[p] <= 0 || n_segments[p] <= 0) {   // empty problem: no centroids, every pixel stays masked
+            g.start_y = g.start_x = 0; g.step_y = g.step_x = 1; g.ny = g.nx = 0;
+            stepmax[p] = 1.0;
+            P.cent_off = cent_off;
+            continue;
+        }
+        long long n_eff = n_segments[p];
+        if (b.masked) {
+            double ne = std::nearbyint((double)n_segments[p] * ((double)P.H * (double)P.W) / (double)nvalid[p]);
+            n_eff = ne < 1.0 ? 1 : (long long)ne;
+        }
+        long long gr[4];
+        regular_grid_hw(P.H, P.W, n_eff, gr);
+        g.start_y = (int)gr[0]; g.step_y = gr[1] ? (int)gr[1] : 1; g.ny = (int)slice_len(P.H, gr[0], gr[1]);
+        g.start_x = (int)gr[2]; g.step_x = gr[3] ? (int)gr[3] : 1; g.nx = (int)slice_len(P.W, gr[2], gr[3]);
+        double sy = gr[1] ? (double)gr[1] : 1.0, sx = gr[3] ? (double)gr[3] : 1.0;
+        stepmax[p] = sy > sx ? sy : sx;   // max(steps); the depth axis contributes 1.0
+        if (stepmax[p] < 1.0) stepmax[p] = 1.0;
+        P.cent_off = cent_off;
+        long long Kg = (long long)g.ny * g.nx;
+        if (Kg < 1) Kg = 1;   // masked fallback seed
+        if (cent_off + Kg > 0x7fff0000LL) { set_error("too many centroids in one batch"); return OBIA_E_INVALID; }
+        cent_off += (int)Kg;
+    }
+    b.total_cent = cent_off > 0 ? cent_off : 1;
+    b.d_seed = A.get<float>((size_t)b.total_cent * 2);
+    b.d_cent_prob = A.get<int>(b.total_cent);
+    SeedGrid *d_grids = A.get<SeedGrid>(np);
+    if (!b.d_seed || !b.d_cent_prob || !d_grids) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_cent_prob, 0xff, sizeof(int) * b.total_cent, ctx->stream));
+    OBIA_HIP_TRY(hipMemcpyAsync(d_grids, grids.data(), sizeof(SeedGrid) * np, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int> K(np);
+    if (b.masked) {
+        int *d_K = A.get<int>(np);
+        if (!d_K) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(seed_masked_kernel, dim3(np), dim3(256), 0, ctx->stream, d_grids, b.d_probs, b.d_mask,
+                           b.d_seed, b.d_cent_prob, d_K);
+        OBIA_TRY(read_back(ctx, K.data(), d_K, sizeof(int) * np));
+        for (int p = 0; p < np; ++p) if (nvalid[p] <= 0 || n_segments[p] <= 0) K[p] = 0;
+    } else {
+        int maxK = 1;
+        for (int p = 0; p < np; ++p) { K[p] = grids[p].ny * grids[p].nx; if (K[p] > maxK) maxK = K[p]; }
+        hipLaunchKernelGGL(seed_grid_kernel, dim3(cdiv(maxK, 256), np), dim3(256), 0, ctx->stream, d_grids, np,
+                           b.d_seed, b.d_cent_prob);
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // grids/probs host vectors are pageable
+    }
+    // window steps, bins, tiles
+    int cell_off = 0, tile_max = 0;
+    for (int p = 0; p < np; ++p) {
+        SlicProblem &P = b.probs[p];
+        P.K = K[p];
+        long long gr[4] = {0, 0, 0, 0};
+        if (P.K > 0) regular_grid_hw(P.H, P.W, P.K, gr);
+        P.sy = gr[1] ? (int)gr[1] : 1;
+        P.sx = gr[3] ? (int)gr[3] : 1;
+        P.ncy = cdiv(P.H, P.sy);
+        P.ncx = cdiv(P.W, P.sx);
+        const float stepf = (float)stepmax[p];
+        P.spatial_w = (float)(1.0 / ((double)stepf * (double)stepf));
+        P.cell_off = cell_off;
+        long long nc = (long long)P.ncy * P.ncx;
+        if (cell_off + nc > 0x7fff0000LL) { set_error("too many bins in one batch"); return OBIA_E_INVALID; }
+        cell_off += (int)nc;
+        P.tiles_x = cdiv(P.W, TW);
+        P.tiles_y = cdiv(P.H, TH);
+        P.tile_off = 0;
+        const int nt = P.tiles_x * P.tiles_y;
+        if (nt > tile_max) tile_max = nt;
+    }
+    b.total_cells = cell_off > 0 ? cell_off : 1;
+    b.total_tiles = tile_max;
+    OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int RS = REC + b.CP;
+    b.d_cent = A.get<float>((size_t)b.total_cent * RS);
+    b.d_head = A.get<int>(b.total_cells);
+    b.d_next = A.get<int>(b.total_cent);
+    b.d_acc_n = A.get<unsigned>((size_t)b.total_cent * 3);
+    b.d_acc_y = b.d_acc_n + b.total_cent;
+    b.d_acc_x = b.d_acc_y + b.total_cent;
+    b.d_acc_f = A.get<long long>((size_t)b.total_cent * b.CP);
+    if (!b.d_cent || !b.d_head || !b.d_next || !b.d_acc_n || !b.d_acc_f) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_acc_n, 0, sizeof(unsigned) * 3 * b.total_cent, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_acc_f, 0, sizeof(long long) * (size_t)b.total_cent * b.CP, ctx->stream));
+    return OBIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-sweep kernels
+// ------------------------------------------------------------------------------------------------
+// K3 + binning: finalise centroids from the accumulators (or the seeds on the very first sweep),
+// write the centroid record {cy, cx, y0, y1, x0, x1, -, -, colour[CP]} and push the centroid on the
+// linked list of the bin that holds its current position.  One thread per centroid.
+__global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__restrict__ probs,
+                                                        const int *__restrict__ cent_prob, int total_cent, int CP,
+                                                        int first, const float *__restrict__ seed,
+                                                        unsigned *__restrict__ acc_n, unsigned *__restrict__ acc_y,
+                                                        unsigned *__restrict__ acc_x, long long *__restrict__ acc_f,
+                                                        double inv_fscale, float *__restrict__ cent,
+                                                        int *__restrict__ head, int *__restrict__ next) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_cent) return;
+    const int p = cent_prob[k];
+    if (p < 0) return;
+    const SlicProblem P = probs[p];
+    if (k - P.cent_off >= P.K) return;
+    const int RS = REC + CP;
+    float *rec = cent + (size_t)k * RS;
+    float cy, cx;
+    if (first) {
+        cy = seed[2 * (size_t)k];
+        cx = seed[2 * (size_t)k + 1];
+        for (int c = 0; c < CP; ++c) rec[REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
+    } else {
+        const unsigned n = acc_n[k];
+        const float fn = (float)n;
+        // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
+        cy = (float)acc_y[k] / fn;
+        cx = (float)acc_x[k] / fn;
+        for (int c = 0; c < CP; ++c) {
+            const float s = (float)((double)acc_f[(size_t)k * CP + c] * inv_fscale);
+            rec[REC + c] = s / fn;
+            acc_f[(size_t)k * CP + c] = 0;
+        }
+        acc_n[k] = 0; acc_y[k] = 0; acc_x[k] = 0;
+    }
+    rec[0] = cy; rec[1] = cx;
+    int *irec = reinterpret_cast<int *>(rec);
+    if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
+        irec[2] = 0; irec[3] = 0; irec[4] = 0; irec[5] = 0;
+        next[k] = -1;
+        return;
+    }
+    // z/y/x window of _slic_cython: (ssize_t)max(c - 2*step, 0) .. (ssize_t)min(c + 2*step + 1, size)
+    float fy0 = cy - (float)(2 * P.sy); fy0 = (0.0f > fy0) ? 0.0f : fy0;
+    float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
+    float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
+    float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
+    irec[2] = (int)fy0; irec[3] = (int)fy1; irec[4] = (int)fx0; irec[5] = (int)fx1;
+    irec[6] = k; irec[7] = 0;
+    int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
+    by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
+    bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
+    next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+}
+
+__device__ __forceinline__ long long to_fixed(double v, double fscale) { return __double2ll_rn(v * fscale); }
+
+// K2: the sweep.  grid = (max tiles per problem, nprob), 256 threads, 32x32 pixel tile, each lane owns
+// a 1x4 vertical strip (rows lyg*4 .. lyg*4+3 of column lx).
+template <int CP, bool MASKED>
+__global__ __launch_bounds__(NT) void slic_assign_kernel(
+    const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
+    const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
+    int32_t *__restrict__ labels, unsigned *__restrict__ acc_n, unsigned *__restrict__ acc_y,
+    unsigned *__restrict__ acc_x, long long *__restrict__ acc_f, int ignore_color, int accumulate,
+    int start_label, double fscale) {
+    const SlicProblem P = probs[blockIdx.y];
+    const int tile = blockIdx.x;
+    if (tile >= P.tiles_x * P.tiles_y) return;
+    constexpr int RS = REC + CP;
+
+    __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][REC];
+    __shared__ __attribute__((aligned(16))) float s_col[MAXC][CP];
+    __shared__ unsigned s_an[MAXC], s_ay[MAXC], s_ax[MAXC];
+    __shared__ unsigned long long s_af[MAXC][CP];
+    __shared__ int s_cnt;
+
+    const int tid = threadIdx.x;
+    const int ty0 = (tile / P.tiles_x) * TH, tx0 = (tile % P.tiles_x) * TW;
+    const int ty1 = min(ty0 + TH, P.H), tx1 = min(tx0 + TW, P.W);
+    const int lx = tid & 31, lyg = tid >> 5;
+    const int x = tx0 + lx, yb = ty0 + lyg * PPT;
+
+    for (int i = tid; i < MAXC; i += NT) { s_an[i] = 0; s_ay[i] = 0; s_ax[i] = 0; }
+    for (int i = tid; i < MAXC * CP; i += NT) (&s_af[0][0])[i] = 0ull;
+    if (tid == 0) s_cnt = 0;
+
+    // ---- load this lane's pixels -----------------------------------------------------------------
+    float f[PPT][CP];
+    bool valid[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int y = yb + j;
+        bool v = (y < P.H) && (x < P.W);
+        const long long pix = P.pix_off + (long long)y * P.W + x;
+        if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
+        valid[j] = v;
+        if (v) {
+            const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
+#pragma unroll
+            for (int q = 0; q < CP / 4; ++q) {
+                const float4 t = src[q];
+                f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
+        }
+    }
+    float best_d[PPT];
+    int best_k[PPT], best_s[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) { best_d[j] = INFINITY; best_k[j] = -1; best_s[j] = -1; }
+
+    // ---- bins whose centroids can reach this tile ------------------------------------------------
+    // candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H))
+    // that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel of slack covers float rounding.
+    int by_lo = (ty0 - 2 * P.sy - 2) / P.sy; if (ty0 - 2 * P.sy - 2 < 0) by_lo = 0;
+    int by_hi = (ty1 + 2 * P.sy + 1) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
+    int bx_lo = (tx0 - 2 * P.sx - 2) / P.sx; if (tx0 - 2 * P.sx - 2 < 0) bx_lo = 0;
+    int bx_hi = (tx1 + 2 * P.sx + 1) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
+    const int nbw = bx_hi - bx_lo + 1;
+    const int nbins = (by_hi - by_lo + 1) * nbw;
+    const float w = P.spatial_w;
+    const float fx = (float)x;
+    int rounds = 0;
+
+    for (int b0 = 0; b0 < nbins; b0 += NT) {
+        int cur = -1;
+        if (b0 + tid < nbins) {
+            const int bi = b0 + tid;
+            cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
+        }
+        int more;
+        do {
+            __syncthreads();   // s_cnt reset / previous round fully consumed
+            // ---- stage: every lane walks the list of its bin ---------------------------------------
+            while (cur >= 0) {
+                const int *irec = reinterpret_cast<const int *>(cent + (size_t)cur * RS);
+                const int y0 = irec[2], y1 = irec[3], x0 = irec[4], x1 = irec[5];
+                if (!(y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0)) { cur = next[cur]; continue; }
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot >= MAXC) break;
+                const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
+                float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
+                dh[0] = src[0]; dh[1] = src[1];
+                float4 *dc = reinterpret_cast<float4 *>(&s_col[slot][0]);
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) dc[q] = src[2 + q];
+                cur = next[cur];
+            }
+            more = __syncthreads_or(cur >= 0);
+            const int nc = min(s_cnt, MAXC);
+            ++rounds;
+            // ---- evaluate ----------------------------------------------------------------------------
+            for (int c = 0; c < nc; ++c) {
+                const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
+                const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+                const float cy = h0.x, cx = h0.y;
+                const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
+                const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
+                const int kk = __float_as_int(h1.z);
+                const bool inx = (x >= x0) && (x < x1);
+                const float tx = cx - fx;
+                const float dx2 = tx * tx;
+                bool need[PPT];
+                float dsp[PPT];
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const int y = yb + j;
+                    const float tyv = cy - (float)y;
+                    const float dy2 = tyv * tyv;
+                    dsp[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
+                    // colour >= 0 and float add is monotone, so d >= dsp: a candidate whose spatial part
+                    // already exceeds the best distance cannot win (equality could still tie on k)
+                    need[j] = valid[j] && inx && (y >= y0) && (y < y1) && !(dsp[j] > best_d[j]);
+                    any |= need[j];
+                }
+                if (!any) continue;
+                float col[CP];
+                if (!ignore_color) {
+#pragma unroll
+                    for (int q = 0; q < CP / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
+                        col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    if (!need[j]) continue;
+                    float d = dsp[j];
+                    if (!ignore_color) {
+                        float dc = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) {
+                            const float t = f[j][ch] - col[ch];
+                            dc += t * t;
+                        }
+                        d += dc;
+                    }
+                    // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k)
+                    if (d < best_d[j] || (d == best_d[j] && kk < best_k[j])) { best_d[j] = d; best_k[j] = kk; best_s[j] = c; }
+                }
+            }
+            if (more) {
+                __syncthreads();
+                if (tid == 0) s_cnt = 0;
+            }
+        } while (more);
+        if (b0 + NT < nbins) {
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+        }
+    }
+    const int nc_last = min(s_cnt, MAXC);
+    const bool single = (rounds == 1);   // slots identify centroids only when one round staged everything
+
+    // ---- labels + fused accumulation -----------------------------------------------------------------
+    double rf[CP];
+    unsigned rn = 0, ry = 0;
+    int rkey = -1;          // slot (single) or centroid id (multi-round)
+    auto flush = [&](int key, unsigned n, unsigned sumy, const double *sf) {
+        if (single) {
+            atomicAdd(&s_an[key], n);
+            atomicAdd(&s_ay[key], sumy);
+            atomicAdd(&s_ax[key], n * (unsigned)x);
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_af[key][ch], (unsigned long long)to_fixed(sf[ch], fscale));
+        } else {
+            atomicAdd(&acc_n[key], n);
+            atomicAdd(&acc_y[key], sumy);
+            atomicAdd(&acc_x[key], n * (unsigned)x);
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc_f[(size_t)key * CP + ch]),
+                          (unsigned long long)to_fixed(sf[ch], fscale));
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int y = yb + j;
+        const bool inimg = (y < P.H) && (x < P.W);
+        const long long pix = P.pix_off + (long long)y * P.W + x;
+        int k = best_k[j];
+        int key = single ? best_s[j] : k;
+        if (inimg) {
+            if (valid[j] && k < 0) {
+                // no window reaches this pixel: `nearest` keeps the previous sweep's value (it is only
+                // initialised once, before the loop) and the pixel is accumulated under it
+                const int prev = labels[pix];
+                if (prev >= start_label) {
+                    const int kp = prev - start_label + P.cent_off;
+                    if (accumulate) {
+                        double one[CP];
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) one[ch] = (double)f[j][ch];
+                        atomicAdd(&acc_n[kp], 1u);
+                        atomicAdd(&acc_y[kp], (unsigned)y);
+                        atomicAdd(&acc_x[kp], (unsigned)x);
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch)
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&acc_f[(size_t)kp * CP + ch]),
+                                      (unsigned long long)to_fixed(one[ch], fscale));
+                    }
+                }
+                key = -1;
+            } else {
+                labels[pix] = (k >= 0) ? (k - P.cent_off + start_label) : (start_label - 1);
+            }
+        }
+        if (!accumulate) continue;
+        const bool a = valid[j] && k >= 0;
+        const int kj = a ? key : -1;
+        if (kj != rkey) {
+            if (rkey >= 0) flush(rkey, rn, ry, rf);
+            rkey = kj; rn = 0; ry = 0;
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+        }
+        if (a) {
+            rn += 1; ry += (unsigned)y;
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
+        }
+    }
+    if (!accumulate) return;
+    if (rkey >= 0) flush(rkey, rn, ry, rf);
+    if (!single) return;
+    __syncthreads();
+    // ---- LDS partials -> global accumulators ------------------------------------------------------------
+    constexpr int NF = 3 + CP;
+    for (int i = tid; i < nc_last * NF; i += NT) {
+        const int slot = i / NF, fld = i % NF;
+        const unsigned n = s_an[slot];
+        if (n == 0) continue;
+        const int k = __float_as_int(s_hdr[slot][6]);
+        if (fld == 0) atomicAdd(&acc_n[k], n);
+        else if (fld == 1) atomicAdd(&acc_y[k], s_ay[slot]);
+        else if (fld == 2) atomicAdd(&acc_x[k], s_ax[slot]);
+        else atomicAdd(reinterpret_cast<unsigned long long *>(&acc_f[(size_t)k * CP + (fld - 3)]), s_af[slot][fld - 3]);
+    }
+}
+
+template <int CP>
+static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate) {
+    dim3 grid(b.total_tiles, b.nprob);
+    if (b.masked)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, true>), grid, dim3(NT), 0, ctx->stream, b.d_probs,
+                           b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc_n, b.d_acc_y,
+                           b.d_acc_x, b.d_acc_f, ignore_color, accumulate, b.start_label, b.fscale);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, false>), grid, dim3(NT), 0, ctx->stream, b.d_probs,
+                           b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc_n, b.d_acc_y,
+                           b.d_acc_x, b.d_acc_f, ignore_color, accumulate, b.start_label, b.fscale);
+}
+
+int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
+    // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
+    {
+        long long n = b.total_pix;
+        int blocks = cdiv(n, 256 * 8);
+        if (blocks > 65535) blocks = 65535;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
+    }
+    if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
+    const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
+    bool first = true;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
+        const bool last_pass = (pass == passes - 1);
+        for (int it = 0; it < b.max_iter; ++it) {
+            OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));
+            hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
+                               b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, b.d_seed, b.d_acc_n, b.d_acc_y, b.d_acc_x,
+                               b.d_acc_f, 1.0 / b.fscale, b.d_cent, b.d_head, b.d_next);
+            first = false;
+            // the update after the very last sweep is never read: skip its accumulation
+            const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
+            {
+                ScopedSpan span(ctx, T_ASSIGN);
+                switch (b.CP) {
+                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate); break;
+                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate); break;
+                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate); break;
+                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate); break;
+                    default: set_error("bad CP"); return OBIA_E_INVALID;
+                }
+            }
+        }
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    return OBIA_OK;
+}
+
+}  // namespace obia
