@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the obia hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits one GPU):
+  16384 x 16384 x 8-band float32 synthetic raster, create_tiled_segments(tile_size=2048, buffer=64,
+  crown_radius=5, pixel size 0.5 m, all-ones mask, compactness=10)  +  zonal mean/var/min/max on all 8 bands.
+One "step" = that whole pipeline once, input already resident in HBM.  value = H*W / step time (Mpixel/s).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu]
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; every rank owns one slab of
+the BASELINE configs[3] raster (32768 columns x 32768/8 rows, 8 bands) -- fixed work per GPU (weak scaling).
+
+The JSON line carries `roofline` (dominant kernel = the SLIC colour sweep slic_assign_kernel<8,true,false>:
+algorithmic bytes (4*C + 4 = 36 B/pixel) x pixels per launch / launch time from HIP events on
+the library's stream) and `cpu_baseline` (the C oracle -- a port, 1 thread -- on one 2048^2 tile of the same
+workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy reaches
+
+
+def synth_raster(H, W, C, seed, device, row0=0):
+    """BASELINE.md 3 generator, on the device: band_c = 400 sin(x/(11+3c)) cos(y/(13+2c)) + 1000 + 50c + N(0,20^2)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty((H, W, C), device=device, dtype=torch.float32)
+    xx = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+    rows = 2048
+    for y0 in range(0, H, rows):
+        h = min(rows, H - y0)
+        yy = torch.arange(row0 + y0, row0 + y0 + h, device=device, dtype=torch.float32)[:, None]
+        for c in range(C):
+            out[y0:y0 + h, :, c] = 400.0 * torch.sin(xx / (11 + 3 * c)) * torch.cos(yy / (13 + 2 * c)) + 1000 + 50 * c \
+                + 20.0 * torch.randn((h, W), device=device, generator=g)
+    return out
+
+
+def cpu_baseline(C, tile, buffer_, crown_radius, pixel, compactness):
+    """The oracle (C port of the reference's arithmetic, single thread) on ONE tile of the same workload:
+    normalise -> maskSLIC structure (pre-pass + 10 sweeps) -> connectivity -> zonal statistics."""
+    from oracle import oracle as orc
+    import math
+    orc.build()
+    rs = np.random.RandomState(0)
+    H = W = tile
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    raw = np.empty((H, W, C), np.float32)
+    for c in range(C):
+        raw[:, :, c] = 400.0 * np.sin(xx / (11 + 3 * c)) * np.cos(yy / (13 + 2 * c)) + 1000 + 50 * c + rs.normal(0, 20, (H, W))
+    mask = np.ones((H, W), np.uint8)
+    n = round(H * W * pixel * pixel / (math.pi * crown_radius ** 2))
+    t0 = time.time()
+    lab = orc.slic(orc.normalize(raw), n_segments=n, compactness=compactness, mask=mask)
+    orc.zonal_stats_c(raw, lab, n_labels=int(lab.max()))
+    dt = time.time() - t0
+    return {"value": H * W / dt / 1e6, "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": f"one {tile}x{tile}x{C} tile of the workload (all-ones mask, n_segments={n}): normalise + "
+                      f"spatial pre-pass + 10 SLIC sweeps + connectivity + zonal stats, {dt:.1f} s on 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=16384, help="raster side at N=1 (default: BASELINE configs[2])")
+    ap.add_argument("--tile", type=int, default=2048)
+    ap.add_argument("--buffer", type=int, default=64)
+    ap.add_argument("--bands", type=int, default=8)
+    ap.add_argument("--compactness", type=float, default=10.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: obia_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from obia_amd import _lib
+    from obia_amd.statistics import zonal_stats
+    from obia_amd.tiling import create_tiled_segments
+
+    C = args.bands
+    if world == 1:
+        H = W = args.size
+        workload = f"{H}x{W}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[2])"
+        row0 = 0
+    else:
+        W = 32768
+        H = 32768 // 8          # one slab of BASELINE configs[3] per GPU: fixed work per GPU
+        row0 = rank * H
+        workload = f"{world} slabs of {H}x{W}x{C} (BASELINE configs[3] slab per GPU), tile={args.tile}, overlap={args.buffer}"
+    img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
+    mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
+    ctx = _lib.Context(local_rank)
+    ctx.set_profiling(True)
+    kw = dict(tile_size=args.tile, buffer=args.buffer, crown_radius=5, pixel_size=(0.5, 0.5), compactness=args.compactness, ctx=ctx)
+
+    def step():
+        lab, n = create_tiled_segments(img, input_mask=mask, **kw)
+        t_seg = ctx.timing()
+        st = zonal_stats(img, lab, n_labels=n, ctx=ctx)
+        t_z = ctx.timing()
+        return lab, n, st, t_seg, t_z
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.time()
+    assign_ms = assign_px = sweeps = 0.0
+    parts = {"features_ms": 0.0, "prepass_ms": 0.0, "assign_ms": 0.0, "connectivity_ms": 0.0, "zonal_ms": 0.0}
+    n_seg = 0
+    for _ in range(args.steps):
+        lab, n_seg, st, t_seg, t_z = step()
+        assign_ms += t_seg["assign_ms"]
+        assign_px += t_seg["assign_px"]
+        sweeps += t_seg["sweeps"]
+        for k in ("features_ms", "prepass_ms", "assign_ms", "connectivity_ms"):
+            parts[k] += t_seg[k]
+        parts["zonal_ms"] += t_z["zonal_ms"]
+    barrier()
+    dt = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    total_px = float(H) * W * world
+    value = total_px / (dt / args.steps) / 1e6
+
+    if rank == 0:
+        bytes_per_px = 4 * C + 4
+        avg_launch_ms = assign_ms / max(1.0, sweeps)
+        achieved = (assign_px * bytes_per_px) / (assign_ms * 1e-3) / 1e9 if assign_ms > 0 else 0.0
+        out = {
+            "metric": "Mpixel/s (SLIC+zonal feats) on 16384²×8-band; achieved HBM GB/s fraction",
+            "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,
+                       "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
+                       "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu"},
+            "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_pixel": bytes_per_px, "launches": int(sweeps), "avg_launch_ms": round(avg_launch_ms, 4),
+                         "pixels_per_launch_avg": round(assign_px / max(1.0, sweeps), 1)},
+            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in parts.items()},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(C, args.tile, args.buffer, 5, 0.5, args.compactness)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

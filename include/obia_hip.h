@@ -138,8 +138,9 @@ int obia_tiled_slic_f32(obia_ctx *ctx, const float *img_hwc, const uint8_t *mask
 
 /* ---- measurement hooks ------------------------------------------------------------------------------
  * Time of the most recent call's kernels by class, measured with HIP events on the context's
- * stream (bench.py's roofline leg).  `what`: 0 = SLIC assign sweeps (sum), 1 = number of sweeps,
- * 2 = feature preparation, 3 = connectivity, 4 = zonal statistics, 5 = whole call.  Milliseconds.    */
+ * stream (bench.py's roofline leg).  `what`: 0 = SLIC colour sweeps (sum of launches, ms), 1 = number of
+ * those launches, 2 = feature preparation, 3 = connectivity, 4 = zonal statistics, 5 = whole call,
+ * 6 = maskSLIC spatial-only pre-pass sweeps (ms), 7 = pixels covered by the launches of 0 (sum).      */
 int obia_set_profiling(obia_ctx *ctx, int enabled);
 double obia_last_timing(obia_ctx *ctx, int what);
 

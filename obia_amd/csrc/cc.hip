@@ -21,6 +21,16 @@
 
 namespace obia {
 
+// dense pixel index -> problem (binary search on pix_off; used on roots / small components only)
+__device__ __forceinline__ int find_prob(const CcProblem *__restrict__ probs, int nprob, long long g) {
+    int lo = 0, hi = nprob - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (probs[mid].pix_off <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ int ld_agent(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -44,32 +54,37 @@ __device__ __forceinline__ void unite(int *parent, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void cc_init_kernel(const int32_t *__restrict__ lab, int *__restrict__ parent,
-                                                      int *__restrict__ size, int H, int W, int mask_label) {
-    const long long n = (long long)H * W;
+__global__ __launch_bounds__(256) void cc_init_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
+                                                      int *__restrict__ parent, int *__restrict__ size, int mask_label) {
+    const CcProblem P = probs[blockIdx.y];
+    const long long n = (long long)P.H * P.W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int l = lab[i];
-        int p = (int)i;
+        const long long g = P.pix_off + i;
+        const int l = lab[g];
+        int p = (int)g;
         // start every pixel at the head of its horizontal run where that is one step away
         if (l == mask_label) p = -1;
-        else if ((int)(i % W) > 0 && lab[i - 1] == l) p = (int)i - 1;
-        parent[i] = p;
-        size[i] = 0;
+        else if ((int)(i % P.W) > 0 && lab[g - 1] == l) p = (int)g - 1;
+        parent[g] = p;
+        size[g] = 0;
     }
 }
 
-__global__ __launch_bounds__(256) void cc_union_kernel(const int32_t *__restrict__ lab, int *__restrict__ parent,
-                                                       int H, int W, int mask_label) {
-    const long long n = (long long)H * W;
+__global__ __launch_bounds__(256) void cc_union_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
+                                                       int *__restrict__ parent, int mask_label) {
+    const CcProblem P = probs[blockIdx.y];
+    const long long n = (long long)P.H * P.W;
+    const int W = P.W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int l = lab[i];
+        const long long g = P.pix_off + i;
+        const int l = lab[g];
         if (l == mask_label) continue;
         const int y = (int)(i / W);
-        if (y > 0 && lab[i - W] == l) {
+        if (y > 0 && lab[g - W] == l) {
             // only the first pixel of a horizontal contact needs to issue the union
             const int x = (int)(i % W);
-            const bool left_same = x > 0 && lab[i - 1] == l && lab[i - W - 1] == l;
-            if (!left_same) unite(parent, (int)i, (int)(i - W));
+            const bool left_same = x > 0 && lab[g - 1] == l && lab[g - W - 1] == l;
+            if (!left_same) unite(parent, (int)g, (int)(g - W));
         }
     }
 }
@@ -96,13 +111,9 @@ __global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ paren
 
 constexpr int SCAN_NT = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_NT * SCAN_PER;
 
-// flag(i) = pixel i is the root of a surviving component
-__device__ __forceinline__ int survivor_flag(const int *parent, const int *size, long long i, int min_size) {
-    return (parent[i] == (int)i && size[i] >= min_size) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const int *__restrict__ parent, const int *__restrict__ size,
-                                                                   long long n, int min_size, int *__restrict__ block_sums,
+__global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                                   const int *__restrict__ parent, const int *__restrict__ size,
+                                                                   long long n, int *__restrict__ block_sums,
                                                                    int *__restrict__ counters /*[0]=n_small [1]=small_px*/) {
     __shared__ int s_w[SCAN_NT / 64];
     const long long base = (long long)blockIdx.x * SCAN_CHUNK;
@@ -111,6 +122,7 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const int *__
         const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
         if (i < n && parent[i] == (int)i) {
             const int sz = size[i];
+            const int min_size = probs[find_prob(probs, nprob, i)].min_size;
             if (sz >= min_size) c += 1;
             else { nsmall += 1; spx += sz; }
         }
@@ -146,8 +158,9 @@ __global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ bl
 }
 
 // newlab[root] = rank (>= 0) for survivors, -(index+2) for small components (collected in small_list)
-__global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const int *__restrict__ parent, const int *__restrict__ size,
-                                                                long long n, int min_size, const int *__restrict__ block_sums,
+__global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                                const int *__restrict__ parent, const int *__restrict__ size,
+                                                                long long n, const int *__restrict__ block_sums,
                                                                 int *__restrict__ newlab, int *__restrict__ small_list,
                                                                 int *__restrict__ small_qoff, int *__restrict__ counters /*[3]=list cursor [4]=queue cursor*/) {
     __shared__ int s_w[SCAN_NT / 64];
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const int *__res
         int sz = 0;
         if (i < n && parent[i] == (int)i) {
             sz = size[i];
-            flag = sz >= min_size;
+            flag = sz >= probs[find_prob(probs, nprob, i)].min_size;
             small = !flag;
         }
         const unsigned long long bal = __ballot(flag);
@@ -186,27 +199,33 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const int *__res
 }
 
 // BFS of the reference over the component rooted at r, started at `start`; neighbour order
-// (x+1, x-1, y+1, y-1).  A neighbour of another component counts as "already labelled" when that
-// component's first pixel precedes `start` in raster order.  Returns the last such neighbour met.
-__device__ int replay_bfs(const int *__restrict__ parent, int r, int start, int mark, int H, int W,
+// (x+1, x-1, y+1, y-1).  A neighbour pixel of another component counts as "already labelled" when that
+// component was labelled before this BFS started: a surviving component as soon as the scan reached its
+// first pixel (root < start); a small component once one of its own BFS attempts found a labelled
+// neighbour (settle < start; a small component that finds none is written back as 0 == unset when
+// start_label is 1).  Returns the last labelled neighbour met.
+__device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict__ newlab,
+                          const int *__restrict__ settle, int r, int start, int mark, int H, int W, int base,
                           int *__restrict__ q, int32_t *__restrict__ out, int *n_out) {
     int head = 0, tail = 1, adjacent = -1;
     q[0] = start;
     out[start] = mark;
     while (head < tail) {
         const int p = q[head++];
-        const int y = p / W, x = p - y * W;
+        const int y = (p - base) / W, x = (p - base) - y * W;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
             const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const int nb = yy * W + xx;
+            const int nb = base + yy * W + xx;
             const int rn = parent[nb];
             if (rn == r) {
                 if (out[nb] != mark) { out[nb] = mark; q[tail++] = nb; }
-            } else if (rn >= 0 && rn < start) {
-                adjacent = nb;     // the LAST labelled neighbour met wins
+            } else if (rn >= 0) {
+                const int nl = newlab[rn];
+                const int since = (nl >= 0) ? rn : settle[-nl - 2];
+                if (since < start) adjacent = nb;     // the LAST labelled neighbour met wins
             }
         }
     }
@@ -214,22 +233,30 @@ __device__ int replay_bfs(const int *__restrict__ parent, int r, int start, int 
     return adjacent;
 }
 
-// One lane replays the reference BFS of one small component.  `out` doubles as the visited map
-// (it is rewritten by the final relabel pass).  target[s] = adjacent pixel, or -1.
-__global__ __launch_bounds__(64) void cc_small_bfs_kernel(const int *__restrict__ parent,
+// One lane replays the reference's treatment of one small component: BFS from its first pixel; if no
+// labelled neighbour is found and start_label is 1 the component is written back as 0 (== unset), the
+// raster scan meets it again at its next pixel and the BFS is replayed from there.  settle_out[s] = start
+// pixel of the attempt that found a neighbour (INT_MAX if none), target[s] = that neighbour pixel.
+// `out` doubles as the visited map (rewritten by the final relabel pass).  Rounds are Jacobi iterations
+// on `settle` (small components adjacent to other small components); *changed reports progress.
+__global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                          const int *__restrict__ parent, const int *__restrict__ newlab,
                                                           const int *__restrict__ small_list, const int *__restrict__ small_qoff,
-                                                          int n_small, int H, int W, int start_label,
+                                                          int n_small, int start_label,
+                                                          const int *__restrict__ settle_in, int *__restrict__ settle_out,
                                                           int *__restrict__ queue, int32_t *__restrict__ out,
-                                                          int *__restrict__ target) {
+                                                          int *__restrict__ target, int *__restrict__ changed) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_small) return;
     const int r = small_list[s];
+    const CcProblem P = probs[find_prob(probs, nprob, r)];
+    const int H = P.H, W = P.W, base = (int)P.pix_off;
     int *q = queue + small_qoff[s];
     int csize = 0;
-    int adjacent = replay_bfs(parent, r, r, -(s + 2), H, W, q, out, &csize);
+    int start = r;
+    int adjacent = replay_bfs(parent, newlab, settle_in, r, r, -(s + 2), H, W, base, q, out, &csize);
     if (adjacent < 0 && start_label == 1) {
-        // `adjacent = 0` means "unset" when start_label is 1: the reference meets the component again at
-        // its next pixel in raster order and replays the BFS from there (rare: no earlier neighbour).
+        start = 0x7fffffff;
         for (int a = 1; a < csize && adjacent < 0; ++a) {
             for (int i = 1; i < csize; ++i) {   // insertion sort: raster order of the component's pixels
                 const int v = q[i];
@@ -237,13 +264,22 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const int *__restrict_
                 while (j >= 0 && q[j] > v) { q[j + 1] = q[j]; --j; }
                 q[j + 1] = v;
             }
-            const int start = q[a];
+            const int st = q[a];
             for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the last attempt
             int n2 = 0;
-            adjacent = replay_bfs(parent, r, start, -(s + 2), H, W, q, out, &n2);
+            adjacent = replay_bfs(parent, newlab, settle_in, r, st, -(s + 2), H, W, base, q, out, &n2);
+            if (adjacent >= 0) start = st;
         }
     }
+    for (int i = 0; i < csize; ++i) out[q[i]] = 0;
     target[s] = adjacent;
+    settle_out[s] = start;
+    if (settle_in[s] != start) atomicOr(changed, 1);
+}
+
+__global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_small, int *__restrict__ settle) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_small) settle[s] = small_list[s];
 }
 
 // final labels: survivors get rank + start_label; small components follow their adjacency chain
@@ -268,47 +304,74 @@ __global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__
     }
 }
 
-int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size, int max_size,
-                             int start_label, int32_t *labels_out, int *h_n_labels_out) {
-    (void)max_size;
+int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
+                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out) {
     ScopedSpan span(ctx, T_CC);
     Arena &A = ctx->arena;
-    const long long n = (long long)H * W;
-    if (n <= 0 || n > 0x7fffffffLL) { set_error("label map of %lld pixels not supported", n); return OBIA_E_INVALID; }
+    const long long n = total_pix;
+    const int np = (int)probs.size();
+    if (np <= 0 || n <= 0 || n > 0x7fffffffLL) { set_error("label batch of %lld pixels not supported", n); return OBIA_E_INVALID; }
     const int mask_label = start_label - 1;
+    CcProblem *d_probs = A.get<CcProblem>(np);
     int *parent = A.get<int>(n), *size = A.get<int>(n), *newlab = A.get<int>(n);
     const int nb = cdiv(n, SCAN_CHUNK);
     int *block_sums = A.get<int>(nb);
     int *counters = A.get<int>(8);
-    if (!parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
+    if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemcpyAsync(d_probs, probs.data(), sizeof(CcProblem) * np, hipMemcpyHostToDevice, ctx->stream));
     OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+    long long maxpix = 1;
+    for (auto &P : probs) { long long m = (long long)P.H * P.W; if (m > maxpix) maxpix = m; }
+    int gx = cdiv(maxpix, 256 * 4);
+    if (gx > 65535 * 4) gx = 65535 * 4;
     int gs = cdiv(n, 256 * 4);
     if (gs > 65535 * 4) gs = 65535 * 4;
-    hipLaunchKernelGGL(cc_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_in, parent, size, H, W, mask_label);
-    hipLaunchKernelGGL(cc_union_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_in, parent, H, W, mask_label);
+    hipLaunchKernelGGL(cc_init_kernel, dim3(gx, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label);
+    hipLaunchKernelGGL(cc_union_kernel, dim3(gx, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
     hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n);
-    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, parent, size, n, min_size, block_sums, counters);
+    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters);
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
     int hc[8];
-    OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));
+    OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));   // also orders the pageable `probs` upload
     const int n_small = hc[0], small_px = hc[1], n_surv = hc[2];
     int *small_list = A.get<int>(n_small > 0 ? n_small : 1);
     int *small_qoff = A.get<int>(n_small > 0 ? n_small : 1);
     int *target = A.get<int>(n_small > 0 ? n_small : 1);
     int *queue = A.get<int>(small_px > 0 ? small_px : 1);
     if (!small_list || !small_qoff || !target || !queue) return OBIA_E_NOMEM;
-    hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, parent, size, n, min_size, block_sums,
+    hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
                        newlab, small_list, small_qoff, counters);
     if (n_small > 0) {
+        int *settle_a = A.get<int>(n_small), *settle_b = A.get<int>(n_small);
+        if (!settle_a || !settle_b) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
-        hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, parent, small_list,
-                           small_qoff, n_small, H, W, start_label, queue, labels_out, target);
+        hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle_a);
+        // optimistic start (every small component labelled at its first pixel), then Jacobi rounds until the
+        // settle times stop moving; one round settles everything unless small components that find no
+        // labelled neighbour touch each other
+        for (int round = 0; round < 32; ++round) {
+            OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
+                               small_list, small_qoff, n_small, start_label, settle_a, settle_b, queue, labels_out, target,
+                               counters + 5);
+            int changed = 0;
+            OBIA_TRY(read_back(ctx, &changed, counters + 5, sizeof(int)));
+            std::swap(settle_a, settle_b);
+            if (!changed) break;
+        }
     }
     hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
                        mask_label, labels_out);
     OBIA_HIP_TRY(hipGetLastError());
     if (h_n_labels_out) *h_n_labels_out = n_surv;
     return OBIA_OK;
+}
+
+int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size, int max_size,
+                             int start_label, int32_t *labels_out, int *h_n_labels_out) {
+    (void)max_size;   // components are never split at max_size (see the header of this file)
+    std::vector<CcProblem> probs(1, CcProblem{H, W, 0, min_size, 0});
+    return enforce_connectivity_batch(ctx, probs, labels_in, (long long)H * W, start_label, labels_out, h_n_labels_out);
 }
 
 }  // namespace obia

@@ -38,18 +38,23 @@ class Arena {
     template <typename T> T *get(size_t n) { return static_cast<T *>(alloc(n * sizeof(T))); }
     void reset();
     void release();
+    // mark()/rewind(): scoped reuse inside one call (per tile batch)
+    struct Mark { size_t block, used, total; };
+    Mark mark() const;
+    void rewind(const Mark &m);
     size_t capacity() const;
     bool failed() const { return failed_; }
 
   private:
     struct Block { char *p; size_t size; size_t used; };
     std::vector<Block> blocks_;
-    size_t high_water_ = 0, cur_total_ = 0;
+    size_t high_water_ = 0, cur_total_ = 0, cur_ = 0;
     bool failed_ = false;
 };
 
 struct Timing {
-    double assign_ms = 0, feat_ms = 0, cc_ms = 0, zonal_ms = 0, total_ms = 0;
+    double assign_ms = 0, prepass_ms = 0, feat_ms = 0, cc_ms = 0, zonal_ms = 0, total_ms = 0;
+    double assign_px = 0;   // pixels swept by the timed colour sweeps (sum over launches)
     int sweeps = 0;
 };
 
@@ -73,7 +78,7 @@ struct obia_ctx {
 
 namespace obia {
 
-enum TimeKind { T_ASSIGN = 0, T_FEAT = 2, T_CC = 3, T_ZONAL = 4, T_TOTAL = 5 };
+enum TimeKind { T_ASSIGN = 0, T_FEAT = 2, T_CC = 3, T_ZONAL = 4, T_TOTAL = 5, T_PREPASS = 6 };
 
 // Records a HIP event pair around a region of the context's stream when profiling is on; no host
 // synchronisation happens until resolve_timing().

@@ -19,8 +19,8 @@ void set_error(const char *fmt, ...) {
 void *Arena::alloc(size_t bytes) {
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes == 0) bytes = 256;
-    if (!blocks_.empty()) {
-        Block &b = blocks_.back();
+    for (; cur_ < blocks_.size(); ++cur_) {
+        Block &b = blocks_[cur_];
         if (b.size - b.used >= bytes) {
             void *p = b.p + b.used;
             b.used += bytes;
@@ -43,14 +43,31 @@ void *Arena::alloc(size_t bytes) {
         want = bytes;
     }
     blocks_.push_back(Block{static_cast<char *>(p), want, bytes});
+    cur_ = blocks_.size() - 1;
     cur_total_ += bytes;
     if (cur_total_ > high_water_) high_water_ = cur_total_;
     return p;
 }
 
+Arena::Mark Arena::mark() const {
+    Mark m;
+    m.block = cur_ < blocks_.size() ? cur_ : blocks_.size();
+    m.used = m.block < blocks_.size() ? blocks_[m.block].used : 0;
+    m.total = cur_total_;
+    return m;
+}
+
+void Arena::rewind(const Mark &m) {
+    for (size_t i = m.block + 1; i < blocks_.size(); ++i) blocks_[i].used = 0;
+    if (m.block < blocks_.size()) blocks_[m.block].used = m.used;
+    cur_ = m.block;
+    cur_total_ = m.total;
+}
+
 void Arena::reset() {
     failed_ = false;
     cur_total_ = 0;
+    cur_ = 0;
     if (blocks_.size() > 1) {
         // merge: one block large enough for the high-water mark of the previous calls
         size_t total = 0;
@@ -58,7 +75,8 @@ void Arena::reset() {
         for (auto &b : blocks_) (void)hipFree(b.p);
         blocks_.clear();
         void *p = nullptr;
-        if (hipMalloc(&p, total) == hipSuccess) blocks_.push_back(Block{static_cast<char *>(p), total, 0});
+        if (hipMalloc(&p, high_water_ + (high_water_ >> 3)) == hipSuccess) blocks_.push_back(Block{static_cast<char *>(p), high_water_ + (high_water_ >> 3), 0});
+        (void)total;
     } else if (!blocks_.empty()) {
         blocks_[0].used = 0;
     }
@@ -113,6 +131,7 @@ void resolve_timing(obia_ctx *ctx) {
             case T_CC: ctx->timing.cc_ms += ms; break;
             case T_ZONAL: ctx->timing.zonal_ms += ms; break;
             case T_TOTAL: ctx->timing.total_ms += ms; break;
+            case T_PREPASS: ctx->timing.prepass_ms += ms; break;
             default: break;
         }
     }
@@ -223,6 +242,8 @@ double obia_last_timing(obia_ctx *ctx, int what) {
         case 3: return ctx->timing.cc_ms;
         case 4: return ctx->timing.zonal_ms;
         case 5: return ctx->timing.total_ms;
+        case 6: return ctx->timing.prepass_ms;
+        case 7: return ctx->timing.assign_px;
         default: return -1.0;
     }
 }

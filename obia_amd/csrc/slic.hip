@@ -108,7 +108,7 @@ __global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restr
             atomicMin(&s_mn[band], f2key(lo));
             atomicMax(&s_mx[band], f2key(hi));
         }
-        if (bad) atomicOr(nonfinite, 1);
+        if (bad) atomicOr(&nonfinite[p], 1);
     }
     __syncthreads();
     if (tid < C) {
@@ -171,6 +171,8 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
                     const float mx = key2f(keys[((long long)p * C + c) * 2 + 1]);
                     t = (t - mn) / (mx - mn);
                 }
+                if (!(fabsf(t) <= 3.0e38f)) t = 0.0f;   // constant / non-finite band: the problem is rejected on the host
+
             }
             v[c] = t;
         }
@@ -196,36 +198,36 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
 
 
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
-                          int to_lab, float ratio) {
+                          int to_lab, float ratio, std::vector<int> *skip) {
     (void)Hs;
     ScopedSpan span(ctx, T_FEAT);
-    const int C = b.C;
+    const int C = b.C, np = b.nprob;
     if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
-    unsigned *d_keys = ctx->arena.get<unsigned>((size_t)b.nprob * C * 2 + 2);
+    // layout: keys[np][C][2] | nonfinite[np] | maxabs bits
+    const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + np + 1;
+    unsigned *d_keys = ctx->arena.get<unsigned>(ntot);
     if (!d_keys) return OBIA_E_NOMEM;
-    unsigned *d_flags = d_keys + (size_t)b.nprob * C * 2;   // [0] nonfinite flag, [1] max|feature| bits
-    {
-        std::vector<unsigned> init((size_t)b.nprob * C * 2 + 2);
-        for (size_t i = 0; i < (size_t)b.nprob * C; ++i) { init[2 * i] = 0xffffffffu; init[2 * i + 1] = 0u; }
-        init[(size_t)b.nprob * C * 2] = 0; init[(size_t)b.nprob * C * 2 + 1] = 0;
-        OBIA_HIP_TRY(hipMemcpyAsync(d_keys, init.data(), init.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `init` is pageable host memory
-    }
+    unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
+    std::vector<unsigned> host(ntot);
+    for (size_t i = 0; i < (size_t)np * C; ++i) { host[2 * i] = 0xffffffffu; host[2 * i + 1] = 0u; }
+    for (size_t i = nkeys; i < ntot; ++i) host[i] = 0;
+    OBIA_HIP_TRY(hipMemcpyAsync(d_keys, host.data(), ntot * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `host` is pageable memory
     int maxh = 1;
     long long maxpix = 1;
     for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; long long n = (long long)w.h * w.w; if (n > maxpix) maxpix = n; }
     if (normalize) {
-        dim3 grid(maxh < 2048 ? maxh : 2048, b.nprob);
-        hipLaunchKernelGGL(band_minmax_kernel, grid, dim3(FP_NT), 0, ctx->stream, src, Ws, C, b.d_windows, d_keys,
-                           (int *)d_flags);
+        int gx = maxh < 2048 ? maxh : 2048;
+        hipLaunchKernelGGL(band_minmax_kernel, dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C, b.d_windows, d_keys,
+                           (int *)d_nonfinite);
     }
     {
-        int blocks = cdiv(maxpix, 256);
-        if (blocks > 8192) blocks = 8192;
-        dim3 grid(blocks, b.nprob);
+        int blocks = cdiv(maxpix, 256 * 4);
+        if (blocks > 16384) blocks = 16384;
+        dim3 grid(blocks, np);
 #define LAUNCH_FEAT(CPV)                                                                                      \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, ctx->stream, src, Ws, C,    \
-                       b.d_windows, d_keys, normalize, to_lab, ratio, b.d_feat, d_flags + 1)
+                       b.d_windows, d_keys, normalize, to_lab, ratio, b.d_feat, d_maxabs)
         switch (b.CP) {
             case 4: LAUNCH_FEAT(4); break;
             case 8: LAUNCH_FEAT(8); break;
@@ -236,23 +238,29 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
 #undef LAUNCH_FEAT
     }
     OBIA_HIP_TRY(hipGetLastError());
-    // one read-back: min/max keys (constant-band check), non-finite flag, max|feature|
-    std::vector<unsigned> host((size_t)b.nprob * C * 2 + 2);
-    OBIA_TRY(read_back(ctx, host.data(), d_keys, host.size() * sizeof(unsigned)));
+    // one read-back: min/max keys (constant-band check), non-finite flags, max|feature|
+    OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));
     auto k2f = [](unsigned k) { unsigned bb = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &bb, 4); return f; };
+    if (skip) skip->assign(np, 0);
     if (normalize) {
-        if (host[(size_t)b.nprob * C * 2]) { set_error("input raster holds NaN or infinite values"); return OBIA_E_NONFINITE; }
-        for (int p = 0; p < b.nprob; ++p)
-            for (int c = 0; c < C; ++c) {
+        for (int p = 0; p < np; ++p) {
+            bool bad = host[nkeys + p] != 0;
+            int cb = -1;
+            float cv = 0;
+            for (int c = 0; c < C && !bad; ++c) {
                 float mn = k2f(host[((size_t)p * C + c) * 2]), mx = k2f(host[((size_t)p * C + c) * 2 + 1]);
-                if (!(mx > mn)) {
-                    set_error("band %d is constant (%g) in window %d: normalize_band would divide 0 by 0 "
-                              "(obia/segmentation/segment_boundaries.py:16)", c, (double)mn, p);
-                    return OBIA_E_NONFINITE;
-                }
+                if (!(mx > mn)) { cb = c; cv = mn; }
             }
+            if (bad || cb >= 0) {
+                if (skip) { (*skip)[p] = 1; continue; }
+                if (bad) set_error("input raster holds NaN or infinite values");
+                else set_error("band %d is constant (%g): normalize_band would divide 0 by 0 "
+                               "(obia/segmentation/segment_boundaries.py:16)", cb, (double)cv);
+                return OBIA_E_NONFINITE;
+            }
+        }
     }
-    float maxabs; unsigned mb = host[(size_t)b.nprob * C * 2 + 1]; memcpy(&maxabs, &mb, 4);
+    float maxabs; unsigned mb = host[nkeys + np]; memcpy(&maxabs, &mb, 4);
     if (!(maxabs <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
     // fixed-point scale for the colour sums: |feature| * maxcount * 2^s < 2^62
     long long maxcount = 1;
@@ -365,14 +373,12 @@ constexpr int TW = 32, TH = 32, NT = 256, PPT = 4;   // tile, threads, pixels pe
 constexpr int MAXC = 128;                            // LDS candidate slots per round
 constexpr int REC = 8;                               // header dwords of a centroid record
 
-int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments) {
+int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
     const int np = b.nprob;
     Arena &A = ctx->arena;
-    // problems carry H, W, pix_off already (set by the caller); upload a first version for the
-    // counting / seeding kernels
-    b.d_probs = A.get<SlicProblem>(np);
+    nvalid.assign(np, 0);
+    if (!b.d_probs) b.d_probs = A.get<SlicProblem>(np);
     if (!b.d_probs) return OBIA_E_NOMEM;
-    std::vector<int> nvalid(np);
     if (b.masked) {
         OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
         int *d_cnt = A.get<int>(np);
@@ -387,6 +393,19 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     } else {
         for (int p = 0; p < np; ++p) nvalid[p] = b.probs[p].H * b.probs[p].W;
     }
+    return OBIA_OK;
+}
+
+int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments, const std::vector<int> *nvalid_in) {
+    const int np = b.nprob;
+    Arena &A = ctx->arena;
+    // problems carry H, W, pix_off already (set by the caller); upload a first version for the
+    // counting / seeding kernels
+    if (!b.d_probs) b.d_probs = A.get<SlicProblem>(np);
+    if (!b.d_probs) return OBIA_E_NOMEM;
+    std::vector<int> nvalid;
+    if (nvalid_in) nvalid = *nvalid_in;
+    else OBIA_TRY(slic_count_valid(ctx, b, nvalid));
     std::vector<SeedGrid> grids(np);
     std::vector<double> stepmax(np);
     int cent_off = 0;
@@ -546,13 +565,14 @@ __device__ __forceinline__ long long to_fixed(double v, double fscale) { return 
 
 // K2: the sweep.  grid = (max tiles per problem, nprob), 256 threads, 32x32 pixel tile, each lane owns
 // a 1x4 vertical strip (rows lyg*4 .. lyg*4+3 of column lx).
-template <int CP, bool MASKED>
+template <int CP, bool MASKED, bool IGNORE_COLOR>
 __global__ __launch_bounds__(NT) void slic_assign_kernel(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
     int32_t *__restrict__ labels, unsigned *__restrict__ acc_n, unsigned *__restrict__ acc_y,
-    unsigned *__restrict__ acc_x, long long *__restrict__ acc_f, int ignore_color, int accumulate,
+    unsigned *__restrict__ acc_x, long long *__restrict__ acc_f, int accumulate,
     int start_label, double fscale) {
+    constexpr bool ignore_color = IGNORE_COLOR;   // maskSLIC pre-pass: distance = spatial term only
     const SlicProblem P = probs[blockIdx.y];
     const int tile = blockIdx.x;
     if (tile >= P.tiles_x * P.tiles_y) return;
@@ -794,14 +814,13 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
 template <int CP>
 static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate) {
     dim3 grid(b.total_tiles, b.nprob);
-    if (b.masked)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, true>), grid, dim3(NT), 0, ctx->stream, b.d_probs,
-                           b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc_n, b.d_acc_y,
-                           b.d_acc_x, b.d_acc_f, ignore_color, accumulate, b.start_label, b.fscale);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, false>), grid, dim3(NT), 0, ctx->stream, b.d_probs,
-                           b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc_n, b.d_acc_y,
-                           b.d_acc_x, b.d_acc_f, ignore_color, accumulate, b.start_label, b.fscale);
+#define LAUNCH_ASSIGN(M, I)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc_n, b.d_acc_y,          \
+                       b.d_acc_x, b.d_acc_f, accumulate, b.start_label, b.fscale)
+    if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
+    else LAUNCH_ASSIGN(false, false);
+#undef LAUNCH_ASSIGN
 }
 
 int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
@@ -828,7 +847,8 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
             // the update after the very last sweep is never read: skip its accumulation
             const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
             {
-                ScopedSpan span(ctx, T_ASSIGN);
+                ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
+                if (!ignore_color) ctx->timing.assign_px += (double)b.total_pix;
                 switch (b.CP) {
                     case 4: launch_assign<4>(ctx, b, ignore_color, accumulate); break;
                     case 8: launch_assign<8>(ctx, b, ignore_color, accumulate); break;

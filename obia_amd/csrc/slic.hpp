@@ -59,15 +59,28 @@ struct SlicBatch {
 // Feature preparation for every problem of the batch: per-band min/max of its window, then
 // normalise (optional) -> Lab (optional) -> * 1/compactness into d_feat.  `src` is the caller's
 // (Hs,Ws,C) raster.  Returns OBIA_E_NONFINITE for constant / non-finite bands.
+// `skip` (nullable): when given, a problem whose window holds a constant or non-finite band is flagged
+// skip[p] = 1 (its features are zero) instead of failing the whole batch -- the reference's tiler
+// swallows the per-tile ValueError (tiling.py:149-150).
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
-                          int normalize, int to_lab, float compactness);
+                          int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
 
 // Seeds (grid or masked grid), fills K / steps / bins in b.probs, uploads descriptors.
 // n_segments[p] = requested segments of problem p.
-int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments);
+// nvalid (nullable): valid-pixel counts already known to the caller.
+int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments,
+                       const std::vector<int> *nvalid = nullptr);
+// valid (unmasked) pixels per problem: mask.sum() (tiling.py:133, slic_superpixels.py:322)
+int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid);
 
 // Runs the sweeps; labels (pre-connectivity) land in b.d_labels.
 int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b);
+
+// Connectivity enforcement on a batch of dense label maps laid out back to back (pix_off); labels come
+// out consecutive over the whole batch, in problem order then raster order of each component's first pixel.
+struct CcProblem { int H, W; long long pix_off; int min_size; int pad; };
+int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
+                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out);
 
 // Connectivity enforcement on one dense (H,W) label map (device pointers).
 int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size,

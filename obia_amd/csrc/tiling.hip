@@ -1,0 +1,386 @@
+// tiling.hip -- B3: the tiled driver on label rasters.
+//
+// Restates the two tile loops of obia.utils.tiling.create_tiled_segments (tiling.py:103-291), where the
+// reference keeps two growing GeoDataFrames and tests every accumulated polygon against every white tile
+// with shapely predicates (tiling.py:205-231).  Here the state is one global label raster G (0 = no
+// segment) plus a per-segment pixel count, and the predicates are pixel counts:
+//   within(tile_polygon)   <=>  every pixel of the segment lies inside the grown window minus the two
+//                               bottom corner squares           (count inside == segment size)
+//   overlaps(tile_polygon) <=>  some but not all of its pixels do
+// (segments are 4-connected pixel sets, tile_polygon is pixel-aligned, rasterize() uses the pixel-centre
+// rule, so the pixel statements are exactly the polygon statements).
+//   pass 1  "black" tiles ((i/T + j/T) even), exact windows          tiling.py:103-153
+//   pass 2  "white" tiles, windows grown by `buffer` and clamped      tiling.py:156-172
+//           segments within the polygon are dropped and re-segmented  tiling.py:220-231
+//           segments overlapping it are kept and masked out, together with the corner squares
+//                                                                    tiling.py:213-260
+//           n_segments = round(mask.sum() * pixel_area / (pi * crown_radius^2))   tiling.py:126-135
+//   ids 1..N in the order black (survivors), then white              tiling.py:289-290
+// All tiles of a pass (or of one white tile-row) are ONE batch for the SLIC engine and for the
+// connectivity kernels: no per-tile launches, two host read-backs per batch.
+#include "slic.hpp"
+
+#include <cmath>
+
+namespace obia {
+
+struct TileWin { int y0, x0, h, w; long long pix_off; int cly, clx; };   // window, dense offset, corner square (px)
+
+// wave-aggregated histogram add: lanes of a wave that hold the same key add once
+__device__ __forceinline__ void wave_hist_add(unsigned *hist, int key, bool active) {
+    bool todo = active;
+    while (true) {
+        const unsigned long long act = __ballot(todo);
+        if (!act) break;
+        const int leader = __ffsll((long long)act) - 1;
+        const int kk = __shfl(key, leader);
+        const unsigned long long same = __ballot(todo && key == kk);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[kk], (unsigned)__popcll(same));
+        if (key == kk) todo = false;
+    }
+}
+
+__device__ __forceinline__ bool in_corner(const TileWin &t, int y, int x) {
+    return (y >= t.h - t.cly) && (x < t.clx || x >= t.w - t.clx);
+}
+
+// white tiles, step 1: pixels of every existing segment that lie inside the tile polygon
+__global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ G,
+                                                                int Wr, unsigned *__restrict__ inside) {
+    const TileWin t = wins[blockIdx.y];
+    const long long n = (long long)t.h * t.w;
+    const long long nround = ((n + 255) / 256) * 256;
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < nround; i0 += (long long)gridDim.x * 256) {
+        const long long i = i0 + threadIdx.x;
+        int g = 0;
+        if (i < n) {
+            const int y = (int)(i / t.w), x = (int)(i % t.w);
+            if (!in_corner(t, y, x)) g = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+        }
+        wave_hist_add(inside, g, g > 0);
+    }
+}
+
+// step 2: dense tile mask.  black: the input mask.  white: input mask minus kept (overlapping) segments
+// minus the corner squares; segments within the polygon are erased from G (they will be re-segmented).
+__global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restrict__ wins, const uint8_t *__restrict__ inmask,
+                                                        int32_t *__restrict__ G, int Wr, int white,
+                                                        const unsigned *__restrict__ inside, const unsigned *__restrict__ seg_size,
+                                                        uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask) {
+    const TileWin t = wins[blockIdx.y];
+    const long long n = (long long)t.h * t.w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / t.w), x = (int)(i % t.w);
+        const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
+        uint8_t m = inmask ? (inmask[gp] != 0) : 1;
+        if (white) {
+            if (in_corner(t, y, x)) m = 0;
+            else {
+                const int g = G[gp];
+                if (g > 0) {
+                    if (inside[g] == seg_size[g]) { G[gp] = 0; alive[g] = 0; }   // within: dropped
+                    else m = 0;                                                    // overlaps: kept, masked out
+                }
+            }
+        }
+        dmask[t.pix_off + i] = m;
+    }
+}
+
+// step 3: write the new segments of the batch into G with their provisional global ids + size histogram
+__global__ __launch_bounds__(256) void tile_scatter_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ lab,
+                                                           int32_t *__restrict__ G, int Wr, int id_base,
+                                                           unsigned *__restrict__ seg_size) {
+    const TileWin t = wins[blockIdx.y];
+    const long long n = (long long)t.h * t.w;
+    const long long nround = ((n + 255) / 256) * 256;
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < nround; i0 += (long long)gridDim.x * 256) {
+        const long long i = i0 + threadIdx.x;
+        int id = 0;
+        if (i < n) {
+            const int l = lab[t.pix_off + i];
+            if (l > 0) {
+                id = id_base + l;
+                const int y = (int)(i / t.w), x = (int)(i % t.w);
+                G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id;
+            }
+        }
+        wave_hist_add(seg_size, id, id > 0);
+    }
+}
+
+// final ids 1..N: exclusive scan over the alive flags of the provisional ids (single workgroup)
+__global__ __launch_bounds__(1024) void ids_scan_kernel(const uint8_t *__restrict__ alive, int n_ids, int *__restrict__ newid,
+                                                        long long *__restrict__ total) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_ids + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, n_ids);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += alive[i] != 0;
+    s_part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - s;
+    for (int i = lo; i < hi; ++i) { if (alive[i]) { run += 1; newid[i] = run; } else newid[i] = 0; }
+    if (tid == 1023) *total = s_part[1023];
+}
+
+__global__ void ids_apply_kernel(int32_t *__restrict__ G, long long n, const int *__restrict__ newid) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int g = G[i];
+        G[i] = g > 0 ? newid[g] : 0;
+    }
+}
+
+struct TileState {
+    int H, W, C;
+    const float *img;
+    const uint8_t *inmask;
+    int32_t *G;
+    unsigned *seg_size, *inside;
+    uint8_t *alive;
+    int id_cap, next_id;   // provisional ids 1..next_id-1
+    const obia_tiling_params *tp;
+    const obia_slic_params *sp;
+};
+
+static int grid_x(long long maxpix, int per) {
+    int g = cdiv(maxpix, 256LL * per);
+    if (g < 1) g = 1;
+    if (g > 65535) g = 65535;
+    return g;
+}
+
+// One batch of tiles: mask -> features -> plan -> sweeps -> connectivity -> scatter.
+static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &wins, bool white) {
+    const int np = (int)wins.size();
+    if (np == 0) return OBIA_OK;
+    Arena &A = ctx->arena;
+    const Arena::Mark mk = A.mark();
+    SlicBatch b;
+    b.nprob = np;
+    b.C = S.C;
+    b.CP = (S.C + 3) & ~3;
+    b.masked = true;       // the tiler always hands a mask to slic (tiling.py:137-143): maskSLIC structure
+    b.start_label = 1;
+    b.max_iter = S.sp->max_num_iter;
+    long long off = 0, maxpix = 1;
+    b.probs.resize(np);
+    b.windows.resize(np);
+    for (int p = 0; p < np; ++p) {
+        wins[p].pix_off = off;
+        SlicProblem P{};
+        P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off;
+        b.probs[p] = P;
+        b.windows[p] = SrcWindow{wins[p].y0, wins[p].x0, wins[p].h, wins[p].w, off};
+        const long long n = (long long)wins[p].h * wins[p].w;
+        if (n > maxpix) maxpix = n;
+        off += n;
+    }
+    if (off > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
+    b.total_pix = off;
+    TileWin *d_wins = A.get<TileWin>(np);
+    b.d_windows = A.get<SrcWindow>(np);
+    b.d_mask = A.get<uint8_t>((size_t)off);
+    b.d_feat = A.get<float>((size_t)off * b.CP);
+    b.d_labels = A.get<int32_t>((size_t)off);
+    int32_t *d_final = A.get<int32_t>((size_t)off);
+    if (!d_wins || !b.d_windows || !b.d_mask || !b.d_feat || !b.d_labels || !d_final) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemcpyAsync(d_wins, wins.data(), sizeof(TileWin) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipMemcpyAsync(b.d_windows, b.windows.data(), sizeof(SrcWindow) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (white) {
+        OBIA_HIP_TRY(hipMemsetAsync(S.inside, 0, sizeof(unsigned) * (size_t)S.next_id, ctx->stream));
+        hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_x(maxpix, 8), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
+    }
+    hipLaunchKernelGGL(tile_mask_kernel, dim3(grid_x(maxpix, 8), np), dim3(256), 0, ctx->stream, d_wins, S.inmask, S.G, S.W,
+                       white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+    // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
+    std::vector<int> skip;
+    const int to_lab = (S.C == 3 && S.sp->convert2lab != 0) ? 1 : 0;
+    OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp->compactness), &skip));
+    std::vector<int> nvalid;
+    OBIA_TRY(slic_count_valid(ctx, b, nvalid));
+    std::vector<int> nseg(np);
+    const double pixel_area = S.tp->pixel_width * S.tp->pixel_height;
+    const double crown_area = M_PI * S.tp->crown_radius * S.tp->crown_radius;
+    for (int p = 0; p < np; ++p) {
+        double n;
+        if (S.sp->n_segments > 0)   // extension: explicit n_segments per full tile, scaled by the valid area
+            n = std::nearbyint((double)S.sp->n_segments * (double)nvalid[p] / ((double)S.tp->tile_size * S.tp->tile_size));
+        else
+            n = std::nearbyint((double)nvalid[p] * pixel_area / crown_area);   // Python round(): half to even
+        nseg[p] = (skip[p] || n < 1.0) ? 0 : (n > 2.0e9 ? 2000000000 : (int)n);   // empty tile -> skipped (tiling.py:149-150)
+    }
+    OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, &nvalid));
+    OBIA_TRY(slic_run_sweeps(ctx, b));
+    int n_new = 0;
+    if (S.sp->enforce_connectivity) {
+        std::vector<CcProblem> cps(np);
+        for (int p = 0; p < np; ++p) {
+            const SlicProblem &P = b.probs[p];
+            const double segment_size = P.K > 0 ? (double)P.n_valid / (double)P.K : 1.0;
+            cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp->min_size_factor * segment_size), 0};
+        }
+        OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new));
+    } else {
+        set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)");
+        return OBIA_E_UNSUPPORTED;
+    }
+    if (S.next_id + n_new > S.id_cap) { set_error("segment id capacity exceeded (%d + %d > %d)", S.next_id, n_new, S.id_cap); return OBIA_E_NOMEM; }
+    if (n_new > 0) {
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_x(maxpix, 8), np), dim3(256), 0, ctx->stream, d_wins, d_final, S.G, S.W,
+                           S.next_id - 1, S.seg_size);
+        OBIA_HIP_TRY(hipMemsetAsync(S.alive + S.next_id, 1, (size_t)n_new, ctx->stream));
+        S.next_id += n_new;
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // host vectors of this batch go out of scope
+    A.rewind(mk);
+    return OBIA_OK;
+}
+
+static int tiled_slic_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
+                          const obia_tiling_params *tp, const obia_slic_params *sp, int32_t *labels_out,
+                          int64_t *n_segments_out) {
+    if (!img || !tp || !sp || !labels_out) { set_error("null argument"); return OBIA_E_INVALID; }
+    if (H <= 0 || W <= 0 || C <= 0 || C > 16) { set_error("bad raster shape (%d,%d,%d)", H, W, C); return OBIA_E_INVALID; }
+    if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels: shard it across GPUs"); return OBIA_E_INVALID; }
+    if (tp->tile_size <= 0 || tp->buffer < 0) { set_error("tile_size must be positive and buffer non-negative"); return OBIA_E_INVALID; }
+    if (!(sp->compactness > 0.0) || sp->max_num_iter < 0) { set_error("bad SLIC parameters"); return OBIA_E_INVALID; }
+    if (sp->slic_zero) { set_error("slic_zero=True is not implemented in this version"); return OBIA_E_UNSUPPORTED; }
+    if (sp->n_segments <= 0 && !(tp->crown_radius > 0.0 && tp->pixel_width > 0.0 && tp->pixel_height > 0.0)) {
+        set_error("crown_radius and pixel size must be positive when n_segments is not given");
+        return OBIA_E_INVALID;
+    }
+    const int T = tp->tile_size, B = tp->buffer;
+    Arena &A = ctx->arena;
+    // capacity for provisional ids: every tile can create at most its grid of seeds
+    long long cap = 16;
+    const int ntx = cdiv(W, T), nty = cdiv(H, T);
+    {
+        const double pixel_area = tp->pixel_width * tp->pixel_height;
+        const double crown_area = M_PI * tp->crown_radius * tp->crown_radius;
+        const long long wh = (long long)(T + 2 * B) * (T + 2 * B);
+        double n = sp->n_segments > 0 ? (double)sp->n_segments * (double)wh / ((double)T * T) : (double)wh * pixel_area / crown_area;
+        if (n < 1) n = 1;
+        // masked seeding lays a grid for n_eff ~ n over the window; rounding of the step can add ~(1 + 1/S)^2
+        cap = (long long)(n * 1.5 + 64.0) * (long long)ntx * nty + 16;
+        if (cap > 0x7ffffff0LL) { set_error("too many segments for int32 ids"); return OBIA_E_INVALID; }
+    }
+    TileState S;
+    S.H = H; S.W = W; S.C = C; S.img = img; S.inmask = mask; S.G = labels_out; S.tp = tp; S.sp = sp;
+    S.id_cap = (int)cap; S.next_id = 1;
+    S.seg_size = A.get<unsigned>((size_t)cap);
+    S.inside = A.get<unsigned>((size_t)cap);
+    S.alive = A.get<uint8_t>((size_t)cap);
+    int *newid = A.get<int>((size_t)cap);
+    long long *d_total = A.get<long long>(1);
+    if (!S.seg_size || !S.inside || !S.alive || !newid || !d_total) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(S.seg_size, 0, sizeof(unsigned) * (size_t)cap, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(S.alive, 0, (size_t)cap, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * (size_t)H * W, ctx->stream));
+    // corner squares: side buffer/2 in MAP units (tiling.py:189), i.e. buffer/2/pixel_size pixels; a pixel is
+    // inside when its centre is (rasterize default all_touched=False)
+    int clx = 0, cly = 0;
+    if (B > 0) {
+        const double cl = (double)B / 2.0;
+        clx = (int)std::ceil(cl / (tp->pixel_width > 0 ? tp->pixel_width : 1.0) - 0.5);
+        cly = (int)std::ceil(cl / (tp->pixel_height > 0 ? tp->pixel_height : 1.0) - 0.5);
+        if (clx < 0) clx = 0;
+        if (cly < 0) cly = 0;
+    }
+    // pass 1: black tiles, exact windows
+    std::vector<TileWin> wins;
+    for (int tj = 0; tj < nty; ++tj)
+        for (int ti = 0; ti < ntx; ++ti) {
+            if ((ti + tj) % 2 != 0) continue;
+            TileWin t{tj * T, ti * T, std::min(T, H - tj * T), std::min(T, W - ti * T), 0, 0, 0};
+            if (t.h > 0 && t.w > 0) wins.push_back(t);
+        }
+    OBIA_TRY(run_tile_batch(ctx, S, wins, false));
+    // pass 2: white tiles on grown windows; one batch per tile-row keeps the reference's raster order of
+    // the white tiles (windows of one tile-row never overlap; those of adjacent rows overlap at corners)
+    for (int tj = 0; tj < nty; ++tj) {
+        wins.clear();
+        for (int ti = 0; ti < ntx; ++ti) {
+            if ((ti + tj) % 2 == 0) continue;
+            const int y0 = std::max(0, tj * T - B), y1 = std::min(H, tj * T + T + B);
+            const int x0 = std::max(0, ti * T - B), x1 = std::min(W, ti * T + T + B);
+            TileWin t{y0, x0, y1 - y0, x1 - x0, 0, std::min(cly, y1 - y0), std::min(clx, x1 - x0)};
+            if (t.h > 0 && t.w > 0) wins.push_back(t);
+        }
+        OBIA_TRY(run_tile_batch(ctx, S, wins, true));
+    }
+    // ids 1..N: black survivors first, then white, each in creation order (tiling.py:289-290)
+    hipLaunchKernelGGL(ids_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.alive, S.next_id, newid, d_total);
+    {
+        int g = cdiv((long long)H * W, 256 * 8);
+        if (g > 65535) g = 65535;
+        hipLaunchKernelGGL(ids_apply_kernel, dim3(g), dim3(256), 0, ctx->stream, labels_out, (long long)H * W, newid);
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    long long total = 0;
+    OBIA_TRY(read_back(ctx, &total, d_total, sizeof(long long)));
+    if (n_segments_out) *n_segments_out = total;
+    return OBIA_OK;
+}
+
+}  // namespace obia
+
+using namespace obia;
+
+extern "C" {
+
+int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
+                            const obia_tiling_params *tiling, const obia_slic_params *params, int32_t *labels_out,
+                            int64_t *n_segments_out) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    int rc;
+    {
+        ScopedSpan total(ctx, T_TOTAL);
+        rc = tiled_slic_dev(ctx, img, mask, H, W, C, tiling, params, labels_out, n_segments_out);
+    }
+    if (rc != OBIA_OK) return rc;
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    return OBIA_OK;
+}
+
+int obia_tiled_slic_f32(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
+                        const obia_tiling_params *tiling, const obia_slic_params *params, int32_t *labels_out,
+                        int64_t *n_segments_out) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    if (!img || !labels_out || H <= 0 || W <= 0 || C <= 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
+    const size_t npix = (size_t)H * W;
+    float *d_img = nullptr; uint8_t *d_mask = nullptr; int32_t *d_lab = nullptr;
+    int rc = OBIA_OK;
+    if (hipMalloc(&d_img, npix * C * sizeof(float)) != hipSuccess || hipMalloc(&d_lab, npix * sizeof(int32_t)) != hipSuccess ||
+        (mask && hipMalloc(&d_mask, npix) != hipSuccess)) {
+        set_error("device allocation for host-pointer call failed");
+        rc = OBIA_E_NOMEM;
+    }
+    if (rc == OBIA_OK && hipMemcpyAsync(d_img, img, npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK && mask && hipMemcpyAsync(d_mask, mask, npix, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_E_HIP) set_error("host->device copy failed in obia_tiled_slic_f32");
+    if (rc == OBIA_OK) rc = obia_tiled_slic_f32_dev(ctx, d_img, d_mask, H, W, C, tiling, params, d_lab, n_segments_out);
+    if (rc == OBIA_OK && hipMemcpyAsync(labels_out, d_lab, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+        set_error("device->host copy failed in obia_tiled_slic_f32");
+        rc = OBIA_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_img); (void)hipFree(d_lab); (void)hipFree(d_mask);
+    return rc;
+}
+
+}  // extern "C"

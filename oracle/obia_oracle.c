@@ -302,6 +302,7 @@ int obia_oracle_enforce_connectivity(const int64_t *labels, int64_t H, int64_t W
     const int64_t mask_label = start_label - 1;
     const int64_t npix = H * W;
     int64_t cap = max_size > 0 ? max_size : 1;
+    if (cap > npix + 1) cap = npix + 1;   /* a component never holds more than npix pixels */
     int64_t *coord = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)cap);
     if (!coord) return OBIA_ENOMEM;
     for (int64_t i = 0; i < npix; ++i) out[i] = mask_label;
