@@ -17,6 +17,7 @@
 #include "slic.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace obia {
 
@@ -365,13 +366,7 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const SlicProblem *__r
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&out[p], c);
 }
 
-__global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
-}
 
-constexpr int TW = 32, TH = 32, NT = 256, PPT = 4;   // tile, threads, pixels per thread
-constexpr int MAXC = 128;                            // LDS candidate slots per round
-constexpr int REC = 8;                               // header dwords of a centroid record
 
 int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
     const int np = b.nprob;
@@ -478,8 +473,8 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         long long nc = (long long)P.ncy * P.ncx;
         if (cell_off + nc > 0x7fff0000LL) { set_error("too many bins in one batch"); return OBIA_E_INVALID; }
         cell_off += (int)nc;
-        P.tiles_x = cdiv(P.W, TW);
-        P.tiles_y = cdiv(P.H, TH);
+        P.tiles_x = cdiv(P.W, SWEEP_TILE);
+        P.tiles_y = cdiv(P.H, SWEEP_TILE);
         P.tile_off = 0;
         const int nt = P.tiles_x * P.tiles_y;
         if (nt > tile_max) tile_max = nt;
@@ -488,378 +483,14 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     b.total_tiles = tile_max;
     OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
     OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const int RS = REC + b.CP;
+    const int RS = CENT_REC + b.CP;
     b.d_cent = A.get<float>((size_t)b.total_cent * RS);
     b.d_head = A.get<int>(b.total_cells);
     b.d_next = A.get<int>(b.total_cent);
-    b.d_acc_n = A.get<unsigned>((size_t)b.total_cent * 3);
-    b.d_acc_y = b.d_acc_n + b.total_cent;
-    b.d_acc_x = b.d_acc_y + b.total_cent;
-    b.d_acc_f = A.get<long long>((size_t)b.total_cent * b.CP);
-    if (!b.d_cent || !b.d_head || !b.d_next || !b.d_acc_n || !b.d_acc_f) return OBIA_E_NOMEM;
-    OBIA_HIP_TRY(hipMemsetAsync(b.d_acc_n, 0, sizeof(unsigned) * 3 * b.total_cent, ctx->stream));
-    OBIA_HIP_TRY(hipMemsetAsync(b.d_acc_f, 0, sizeof(long long) * (size_t)b.total_cent * b.CP, ctx->stream));
-    return OBIA_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-sweep kernels
-// ------------------------------------------------------------------------------------------------
-// K3 + binning: finalise centroids from the accumulators (or the seeds on the very first sweep),
-// write the centroid record {cy, cx, y0, y1, x0, x1, -, -, colour[CP]} and push the centroid on the
-// linked list of the bin that holds its current position.  One thread per centroid.
-__global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__restrict__ probs,
-                                                        const int *__restrict__ cent_prob, int total_cent, int CP,
-                                                        int first, const float *__restrict__ seed,
-                                                        unsigned *__restrict__ acc_n, unsigned *__restrict__ acc_y,
-                                                        unsigned *__restrict__ acc_x, long long *__restrict__ acc_f,
-                                                        double inv_fscale, float *__restrict__ cent,
-                                                        int *__restrict__ head, int *__restrict__ next) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= total_cent) return;
-    const int p = cent_prob[k];
-    if (p < 0) return;
-    const SlicProblem P = probs[p];
-    if (k - P.cent_off >= P.K) return;
-    const int RS = REC + CP;
-    float *rec = cent + (size_t)k * RS;
-    float cy, cx;
-    if (first) {
-        cy = seed[2 * (size_t)k];
-        cx = seed[2 * (size_t)k + 1];
-        for (int c = 0; c < CP; ++c) rec[REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
-    } else {
-        const unsigned n = acc_n[k];
-        const float fn = (float)n;
-        // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
-        cy = (float)acc_y[k] / fn;
-        cx = (float)acc_x[k] / fn;
-        for (int c = 0; c < CP; ++c) {
-            const float s = (float)((double)acc_f[(size_t)k * CP + c] * inv_fscale);
-            rec[REC + c] = s / fn;
-            acc_f[(size_t)k * CP + c] = 0;
-        }
-        acc_n[k] = 0; acc_y[k] = 0; acc_x[k] = 0;
-    }
-    rec[0] = cy; rec[1] = cx;
-    int *irec = reinterpret_cast<int *>(rec);
-    if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
-        irec[2] = 0; irec[3] = 0; irec[4] = 0; irec[5] = 0;
-        next[k] = -1;
-        return;
-    }
-    // z/y/x window of _slic_cython: (ssize_t)max(c - 2*step, 0) .. (ssize_t)min(c + 2*step + 1, size)
-    float fy0 = cy - (float)(2 * P.sy); fy0 = (0.0f > fy0) ? 0.0f : fy0;
-    float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
-    float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
-    float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
-    irec[2] = (int)fy0; irec[3] = (int)fy1; irec[4] = (int)fx0; irec[5] = (int)fx1;
-    irec[6] = k; irec[7] = 0;
-    int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
-    by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
-    bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
-    next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
-}
-
-__device__ __forceinline__ long long to_fixed(double v, double fscale) { return __double2ll_rn(v * fscale); }
-
-// K2: the sweep.  grid = (max tiles per problem, nprob), 256 threads, 32x32 pixel tile, each lane owns
-// a 1x4 vertical strip (rows lyg*4 .. lyg*4+3 of column lx).
-template <int CP, bool MASKED, bool IGNORE_COLOR>
-__global__ __launch_bounds__(NT) void slic_assign_kernel(
-    const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
-    const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
-    int32_t *__restrict__ labels, unsigned *__restrict__ acc_n, unsigned *__restrict__ acc_y,
-    unsigned *__restrict__ acc_x, long long *__restrict__ acc_f, int accumulate,
-    int start_label, double fscale) {
-    constexpr bool ignore_color = IGNORE_COLOR;   // maskSLIC pre-pass: distance = spatial term only
-    const SlicProblem P = probs[blockIdx.y];
-    const int tile = blockIdx.x;
-    if (tile >= P.tiles_x * P.tiles_y) return;
-    constexpr int RS = REC + CP;
-
-    __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][REC];
-    __shared__ __attribute__((aligned(16))) float s_col[MAXC][CP];
-    __shared__ unsigned s_an[MAXC], s_ay[MAXC], s_ax[MAXC];
-    __shared__ unsigned long long s_af[MAXC][CP];
-    __shared__ int s_cnt;
-
-    const int tid = threadIdx.x;
-    const int ty0 = (tile / P.tiles_x) * TH, tx0 = (tile % P.tiles_x) * TW;
-    const int ty1 = min(ty0 + TH, P.H), tx1 = min(tx0 + TW, P.W);
-    const int lx = tid & 31, lyg = tid >> 5;
-    const int x = tx0 + lx, yb = ty0 + lyg * PPT;
-
-    for (int i = tid; i < MAXC; i += NT) { s_an[i] = 0; s_ay[i] = 0; s_ax[i] = 0; }
-    for (int i = tid; i < MAXC * CP; i += NT) (&s_af[0][0])[i] = 0ull;
-    if (tid == 0) s_cnt = 0;
-
-    // ---- load this lane's pixels -----------------------------------------------------------------
-    float f[PPT][CP];
-    bool valid[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int y = yb + j;
-        bool v = (y < P.H) && (x < P.W);
-        const long long pix = P.pix_off + (long long)y * P.W + x;
-        if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
-        valid[j] = v;
-        if (v) {
-            const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
-#pragma unroll
-            for (int q = 0; q < CP / 4; ++q) {
-                const float4 t = src[q];
-                f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
-        }
-    }
-    float best_d[PPT];
-    int best_k[PPT], best_s[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) { best_d[j] = INFINITY; best_k[j] = -1; best_s[j] = -1; }
-
-    // ---- bins whose centroids can reach this tile ------------------------------------------------
-    // candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H))
-    // that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel of slack covers float rounding.
-    int by_lo = (ty0 - 2 * P.sy - 2) / P.sy; if (ty0 - 2 * P.sy - 2 < 0) by_lo = 0;
-    int by_hi = (ty1 + 2 * P.sy + 1) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
-    int bx_lo = (tx0 - 2 * P.sx - 2) / P.sx; if (tx0 - 2 * P.sx - 2 < 0) bx_lo = 0;
-    int bx_hi = (tx1 + 2 * P.sx + 1) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
-    const int nbw = bx_hi - bx_lo + 1;
-    const int nbins = (by_hi - by_lo + 1) * nbw;
-    const float w = P.spatial_w;
-    const float fx = (float)x;
-    int rounds = 0;
-
-    for (int b0 = 0; b0 < nbins; b0 += NT) {
-        int cur = -1;
-        if (b0 + tid < nbins) {
-            const int bi = b0 + tid;
-            cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
-        }
-        int more;
-        do {
-            __syncthreads();   // s_cnt reset / previous round fully consumed
-            // ---- stage: every lane walks the list of its bin ---------------------------------------
-            while (cur >= 0) {
-                const int *irec = reinterpret_cast<const int *>(cent + (size_t)cur * RS);
-                const int y0 = irec[2], y1 = irec[3], x0 = irec[4], x1 = irec[5];
-                if (!(y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0)) { cur = next[cur]; continue; }
-                const int slot = atomicAdd(&s_cnt, 1);
-                if (slot >= MAXC) break;
-                const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
-                float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
-                dh[0] = src[0]; dh[1] = src[1];
-                float4 *dc = reinterpret_cast<float4 *>(&s_col[slot][0]);
-#pragma unroll
-                for (int q = 0; q < CP / 4; ++q) dc[q] = src[2 + q];
-                cur = next[cur];
-            }
-            more = __syncthreads_or(cur >= 0);
-            const int nc = min(s_cnt, MAXC);
-            ++rounds;
-            // ---- evaluate ----------------------------------------------------------------------------
-            for (int c = 0; c < nc; ++c) {
-                const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
-                const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
-                const float cy = h0.x, cx = h0.y;
-                const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
-                const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
-                const int kk = __float_as_int(h1.z);
-                const bool inx = (x >= x0) && (x < x1);
-                const float tx = cx - fx;
-                const float dx2 = tx * tx;
-                bool need[PPT];
-                float dsp[PPT];
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    const int y = yb + j;
-                    const float tyv = cy - (float)y;
-                    const float dy2 = tyv * tyv;
-                    dsp[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
-                    // colour >= 0 and float add is monotone, so d >= dsp: a candidate whose spatial part
-                    // already exceeds the best distance cannot win (equality could still tie on k)
-                    need[j] = valid[j] && inx && (y >= y0) && (y < y1) && !(dsp[j] > best_d[j]);
-                    any |= need[j];
-                }
-                if (!any) continue;
-                float col[CP];
-                if (!ignore_color) {
-#pragma unroll
-                    for (int q = 0; q < CP / 4; ++q) {
-                        const float4 t = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
-                        col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    if (!need[j]) continue;
-                    float d = dsp[j];
-                    if (!ignore_color) {
-                        float dc = 0.0f;
-#pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) {
-                            const float t = f[j][ch] - col[ch];
-                            dc += t * t;
-                        }
-                        d += dc;
-                    }
-                    // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k)
-                    if (d < best_d[j] || (d == best_d[j] && kk < best_k[j])) { best_d[j] = d; best_k[j] = kk; best_s[j] = c; }
-                }
-            }
-            if (more) {
-                __syncthreads();
-                if (tid == 0) s_cnt = 0;
-            }
-        } while (more);
-        if (b0 + NT < nbins) {
-            __syncthreads();
-            if (tid == 0) s_cnt = 0;
-        }
-    }
-    const int nc_last = min(s_cnt, MAXC);
-    const bool single = (rounds == 1);   // slots identify centroids only when one round staged everything
-
-    // ---- labels + fused accumulation -----------------------------------------------------------------
-    double rf[CP];
-    unsigned rn = 0, ry = 0;
-    int rkey = -1;          // slot (single) or centroid id (multi-round)
-    auto flush = [&](int key, unsigned n, unsigned sumy, const double *sf) {
-        if (single) {
-            atomicAdd(&s_an[key], n);
-            atomicAdd(&s_ay[key], sumy);
-            atomicAdd(&s_ax[key], n * (unsigned)x);
-#pragma unroll
-            for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_af[key][ch], (unsigned long long)to_fixed(sf[ch], fscale));
-        } else {
-            atomicAdd(&acc_n[key], n);
-            atomicAdd(&acc_y[key], sumy);
-            atomicAdd(&acc_x[key], n * (unsigned)x);
-#pragma unroll
-            for (int ch = 0; ch < CP; ++ch)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc_f[(size_t)key * CP + ch]),
-                          (unsigned long long)to_fixed(sf[ch], fscale));
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int y = yb + j;
-        const bool inimg = (y < P.H) && (x < P.W);
-        const long long pix = P.pix_off + (long long)y * P.W + x;
-        int k = best_k[j];
-        int key = single ? best_s[j] : k;
-        if (inimg) {
-            if (valid[j] && k < 0) {
-                // no window reaches this pixel: `nearest` keeps the previous sweep's value (it is only
-                // initialised once, before the loop) and the pixel is accumulated under it
-                const int prev = labels[pix];
-                if (prev >= start_label) {
-                    const int kp = prev - start_label + P.cent_off;
-                    if (accumulate) {
-                        double one[CP];
-#pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) one[ch] = (double)f[j][ch];
-                        atomicAdd(&acc_n[kp], 1u);
-                        atomicAdd(&acc_y[kp], (unsigned)y);
-                        atomicAdd(&acc_x[kp], (unsigned)x);
-#pragma unroll
-                        for (int ch = 0; ch < CP; ++ch)
-                            atomicAdd(reinterpret_cast<unsigned long long *>(&acc_f[(size_t)kp * CP + ch]),
-                                      (unsigned long long)to_fixed(one[ch], fscale));
-                    }
-                }
-                key = -1;
-            } else {
-                labels[pix] = (k >= 0) ? (k - P.cent_off + start_label) : (start_label - 1);
-            }
-        }
-        if (!accumulate) continue;
-        const bool a = valid[j] && k >= 0;
-        const int kj = a ? key : -1;
-        if (kj != rkey) {
-            if (rkey >= 0) flush(rkey, rn, ry, rf);
-            rkey = kj; rn = 0; ry = 0;
-#pragma unroll
-            for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
-        }
-        if (a) {
-            rn += 1; ry += (unsigned)y;
-#pragma unroll
-            for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
-        }
-    }
-    if (!accumulate) return;
-    if (rkey >= 0) flush(rkey, rn, ry, rf);
-    if (!single) return;
-    __syncthreads();
-    // ---- LDS partials -> global accumulators ------------------------------------------------------------
-    constexpr int NF = 3 + CP;
-    for (int i = tid; i < nc_last * NF; i += NT) {
-        const int slot = i / NF, fld = i % NF;
-        const unsigned n = s_an[slot];
-        if (n == 0) continue;
-        const int k = __float_as_int(s_hdr[slot][6]);
-        if (fld == 0) atomicAdd(&acc_n[k], n);
-        else if (fld == 1) atomicAdd(&acc_y[k], s_ay[slot]);
-        else if (fld == 2) atomicAdd(&acc_x[k], s_ax[slot]);
-        else atomicAdd(reinterpret_cast<unsigned long long *>(&acc_f[(size_t)k * CP + (fld - 3)]), s_af[slot][fld - 3]);
-    }
-}
-
-template <int CP>
-static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate) {
-    dim3 grid(b.total_tiles, b.nprob);
-#define LAUNCH_ASSIGN(M, I)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
-                       b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc_n, b.d_acc_y,          \
-                       b.d_acc_x, b.d_acc_f, accumulate, b.start_label, b.fscale)
-    if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
-    else LAUNCH_ASSIGN(false, false);
-#undef LAUNCH_ASSIGN
-}
-
-int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
-    // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
-    {
-        long long n = b.total_pix;
-        int blocks = cdiv(n, 256 * 8);
-        if (blocks > 65535) blocks = 65535;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
-    }
-    if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
-    const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
-    bool first = true;
-    for (int pass = 0; pass < passes; ++pass) {
-        const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
-        const bool last_pass = (pass == passes - 1);
-        for (int it = 0; it < b.max_iter; ++it) {
-            OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));
-            hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
-                               b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, b.d_seed, b.d_acc_n, b.d_acc_y, b.d_acc_x,
-                               b.d_acc_f, 1.0 / b.fscale, b.d_cent, b.d_head, b.d_next);
-            first = false;
-            // the update after the very last sweep is never read: skip its accumulation
-            const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
-            {
-                ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
-                if (!ignore_color) ctx->timing.assign_px += (double)b.total_pix;
-                switch (b.CP) {
-                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate); break;
-                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate); break;
-                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate); break;
-                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate); break;
-                    default: set_error("bad CP"); return OBIA_E_INVALID;
-                }
-            }
-        }
-    }
-    OBIA_HIP_TRY(hipGetLastError());
+    const size_t acc_q = (size_t)b.total_cent * acc_record_qwords(b.CP);
+    b.d_acc = A.get<unsigned long long>(acc_q);
+    if (!b.d_cent || !b.d_head || !b.d_next || !b.d_acc) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * acc_q, ctx->stream));
     return OBIA_OK;
 }
 

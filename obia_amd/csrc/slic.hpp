@@ -31,6 +31,12 @@ struct SrcWindow {
 // step 0 == slice(None).
 void regular_grid_hw(long long H, long long W, long long n, long long out[4]);
 
+constexpr int SWEEP_TILE = 64;   // pixels per side of the workgroup tile of the sweep kernel
+constexpr int CENT_REC = 8;      // header dwords of a centroid record: cy, cx, y0, y1, x0, x1, k, -
+// Accumulator record of one centroid, 128-byte aligned so a tile's flush touches two 64-B lines:
+//   q[0..CP)  colour sums, 64-bit fixed point     q[CP] = n | (sum_y << 32)     q[CP+1] = sum_x
+inline int acc_record_qwords(int CP) { return CP <= 12 ? 16 : 32; }
+
 struct SlicBatch {
     int nprob = 0;
     int C = 0, CP = 0;                 // bands, bands padded to a multiple of 4
@@ -51,8 +57,7 @@ struct SlicBatch {
     int *d_cent_prob = nullptr;        // [total_cent]
     float *d_cent = nullptr;           // [total_cent][8 + CP] records
     int *d_head = nullptr, *d_next = nullptr;
-    unsigned *d_acc_n = nullptr, *d_acc_y = nullptr, *d_acc_x = nullptr;
-    long long *d_acc_f = nullptr;      // [total_cent][CP] fixed point
+    unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
     double fscale = 1.0;
 };
 

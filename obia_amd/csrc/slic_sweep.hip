@@ -1,0 +1,584 @@
+// slic_sweep.hip -- the per-sweep kernels of the SLIC engine: centroid finalise + binning, and the
+// pixel-centric assign sweep with the centroid update fused in.
+//
+// Restates one iteration of _slic_cython (scikit-image _slic.pyx 0.18.3, reached from
+// obia/segmentation/segment_boundaries.py:51; oracle/obia_oracle.c: obia_oracle_slic_core):
+//   reference: for k ascending: scatter d(k, pixel) into the (4S+1)^2 window of centroid k, keep it where
+//              `distance > d` (ties stay with the lowest k); then sum pixel coordinates and colours per label.
+//   here:      for each pixel: lexicographic minimum of (d, k) over the centroids whose window contains it.
+//              Same candidate set (windows are computed with the reference's float expressions and
+//              truncations), same float32 operation order for d (compiled with -ffp-contract=off), same tie
+//              rule; the sums are exact integers (coordinates) / 64-bit fixed point (colours).
+//
+// Kernel shape (gfx950): one 256-thread workgroup per 64x64 pixel tile.
+//   1. the workgroup stages into LDS the records of every centroid whose window intersects the tile
+//      (lanes walk the per-bin linked lists built by slic_prep_kernel);
+//   2. each wave walks four 16x16 footprints; a lane owns a 1x4 vertical strip.  Lanes first score the
+//      staged candidates in parallel (one candidate per lane): window-intersects-footprint and a lower
+//      bound `lb` of the spatial term over the footprint; candidates are then visited in ascending lb and
+//      the walk stops when lb exceeds the largest current best distance in the wave (d >= spatial >= lb,
+//      float add/mul are monotone, so nothing that is skipped could have won or tied);
+//   3. the centroid update is fused: per-lane run sums (double) are transposed through a conflict-free LDS
+//      scratch so that 16 lanes x (CP+3) fields fold the wave's 64 strips sequentially, and only the few
+//      resulting (centroid, field) partials touch the workgroup's LDS accumulators (64-bit integer
+//      atomics); one packed global atomic record per (tile, centroid) at the end.
+// A tile that meets more candidates than fit in LDS (tiny S, clustered centroids) takes slow_tile(), which
+// reads the bins directly; correctness never depends on the LDS capacity.
+#include "slic.hpp"
+
+#include <cstdlib>
+
+namespace obia {
+
+constexpr int NT = 256;
+constexpr int FB = 16;          // wave footprint side
+constexpr int PPT = 4;          // pixels per lane (vertical strip)
+constexpr int MAXC = 96;        // LDS candidate slots
+
+// K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
+// write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
+// linked list of the bin that holds its current position.  One thread per centroid.
+__global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__restrict__ probs,
+                                                        const int *__restrict__ cent_prob, int total_cent, int CP,
+                                                        int RQ, int first, const float *__restrict__ seed,
+                                                        unsigned long long *__restrict__ acc, double inv_fscale,
+                                                        float *__restrict__ cent, int *__restrict__ head,
+                                                        int *__restrict__ next) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_cent) return;
+    const int p = cent_prob[k];
+    if (p < 0) return;
+    const SlicProblem P = probs[p];
+    if (k - P.cent_off >= P.K) return;
+    const int RS = CENT_REC + CP;
+    float *rec = cent + (size_t)k * RS;
+    float cy, cx;
+    if (first) {
+        cy = seed[2 * (size_t)k];
+        cx = seed[2 * (size_t)k + 1];
+        for (int c = 0; c < CP; ++c) rec[CENT_REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
+    } else {
+        unsigned long long *a = acc + (size_t)k * RQ;
+        const unsigned long long ny = a[CP];
+        const unsigned n = (unsigned)(ny & 0xffffffffull);
+        const float fn = (float)n;
+        // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
+        cy = (float)(unsigned)(ny >> 32) / fn;
+        cx = (float)(unsigned)a[CP + 1] / fn;
+        for (int c = 0; c < CP; ++c) {
+            const float s = (float)((double)(long long)a[c] * inv_fscale);
+            rec[CENT_REC + c] = s / fn;
+            a[c] = 0;
+        }
+        a[CP] = 0; a[CP + 1] = 0;
+    }
+    rec[0] = cy; rec[1] = cx;
+    int *irec = reinterpret_cast<int *>(rec);
+    irec[6] = k; irec[7] = 0;
+    if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
+        irec[2] = 0; irec[3] = 0; irec[4] = 0; irec[5] = 0;
+        next[k] = -1;
+        return;
+    }
+    // z/y/x window of _slic_cython: (ssize_t)max(c - 2*step, 0) .. (ssize_t)min(c + 2*step + 1, size)
+    float fy0 = cy - (float)(2 * P.sy); fy0 = (0.0f > fy0) ? 0.0f : fy0;
+    float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
+    float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
+    float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
+    irec[2] = (int)fy0; irec[3] = (int)fy1; irec[4] = (int)fx0; irec[5] = (int)fx1;
+    int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
+    by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
+    bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
+    next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+}
+
+__device__ __forceinline__ unsigned long long to_fixed(double v, double fscale) {
+    return (unsigned long long)__double2ll_rn(v * fscale);
+}
+
+// ---- wave-wide reductions on DPP (no LDS traffic) ---------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+// non-negative floats order like their bit patterns, so min/max run on unsigned integers
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = max(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = max(v, dpp_u32<0x141>(v));   // row_half_mirror
+    v = max(v, dpp_u32<0x140>(v));   // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// LDS written by some lanes of a wave, read by others of the same wave: the LDS pipe is in order per
+// wave, so a compiler-level fence is all that is needed.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int CP>
+__device__ __forceinline__ void global_accumulate(unsigned long long *__restrict__ acc, int RQ, int k, unsigned n,
+                                                  unsigned sumy, unsigned long long sumx, const double *sf,
+                                                  double fscale) {
+    unsigned long long *a = acc + (size_t)k * RQ;
+#pragma unroll
+    for (int ch = 0; ch < CP; ++ch) atomicAdd(&a[ch], to_fixed(sf[ch], fscale));
+    atomicAdd(&a[CP], (unsigned long long)n | ((unsigned long long)sumy << 32));
+    atomicAdd(&a[CP + 1], sumx);
+}
+
+// Fallback for a tile whose candidate set does not fit the LDS slots: every lane scans the bins around
+// each of its pixels directly in global memory.  Same arithmetic, no staging.
+template <int CP, bool MASKED, bool IGNORE_COLOR>
+__device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *__restrict__ feat,
+                          const uint8_t *__restrict__ mask, const float *__restrict__ cent,
+                          const int *__restrict__ head, const int *__restrict__ next, int32_t *__restrict__ labels,
+                          unsigned long long *__restrict__ acc, int RQ, int accumulate, int start_label, double fscale) {
+    constexpr int RS = CENT_REC + CP;
+    const float w = P.spatial_w;
+    for (int i = threadIdx.x; i < SWEEP_TILE * SWEEP_TILE; i += NT) {
+        const int y = ty0 + i / SWEEP_TILE, x = tx0 + i % SWEEP_TILE;
+        if (y >= P.H || x >= P.W) continue;
+        const long long pix = P.pix_off + (long long)y * P.W + x;
+        if (MASKED && mask[pix] == 0) { labels[pix] = start_label - 1; continue; }
+        float f[CP];
+#pragma unroll
+        for (int ch = 0; ch < CP; ++ch) f[ch] = feat[pix * CP + ch];
+        int by_lo = (y - 2 * P.sy - 2) / P.sy; if (y - 2 * P.sy - 2 < 0) by_lo = 0;
+        int by_hi = (y + 2 * P.sy + 2) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
+        int bx_lo = (x - 2 * P.sx - 2) / P.sx; if (x - 2 * P.sx - 2 < 0) bx_lo = 0;
+        int bx_hi = (x + 2 * P.sx + 2) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
+        float best = INFINITY;
+        int bk = -1;
+        for (int by = by_lo; by <= by_hi; ++by)
+            for (int bx = bx_lo; bx <= bx_hi; ++bx)
+                for (int cur = head[P.cell_off + by * P.ncx + bx]; cur >= 0; cur = next[cur]) {
+                    const float *rec = cent + (size_t)cur * RS;
+                    const int *irec = reinterpret_cast<const int *>(rec);
+                    if (!(y >= irec[2] && y < irec[3] && x >= irec[4] && x < irec[5])) continue;
+                    const float tyv = rec[0] - (float)y, txv = rec[1] - (float)x;
+                    const float dy2 = tyv * tyv, dx2 = txv * txv;
+                    float d = (dy2 + dx2) * w;
+                    if (!IGNORE_COLOR) {
+                        float dc = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) { const float t = f[ch] - rec[CENT_REC + ch]; dc += t * t; }
+                        d += dc;
+                    }
+                    if (d < best || (d == best && cur < bk)) { best = d; bk = cur; }
+                }
+        int k = bk;
+        if (k < 0) {   // `nearest` keeps the previous sweep's value
+            const int prev = labels[pix];
+            if (prev >= start_label) k = prev - start_label + P.cent_off;
+        } else {
+            labels[pix] = k - P.cent_off + start_label;
+        }
+        if (accumulate && k >= 0) {
+            double sf[CP];
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) sf[ch] = (double)f[ch];
+            global_accumulate<CP>(acc, RQ, k, 1u, (unsigned)y, (unsigned long long)x, sf, fscale);
+        }
+    }
+}
+
+// K2: the sweep.  grid = (max tiles per problem, nprob).
+template <int CP, bool MASKED, bool IGNORE_COLOR>
+__global__ __launch_bounds__(NT) void slic_assign_kernel(
+    const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
+    const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
+    int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,
+    int start_label, double fscale) {
+    // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
+    // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
+    // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
+    const SlicProblem P = probs[blockIdx.y];
+    const int tile = blockIdx.x;
+    if (tile >= P.tiles_x * P.tiles_y) return;
+    constexpr int RS = CENT_REC + CP;
+    constexpr int AQ = CP + 2;                  // qwords of an LDS accumulator: colours, n|sum_y<<32, sum_x
+    constexpr int NF = CP + 3;                  // transposed fields: colours, n, sum_y, sum_x (as doubles)
+    constexpr int NPASS = (NF + 15) / 16;
+
+    __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
+    __shared__ __attribute__((aligned(16))) float s_col[MAXC][CP];
+    __shared__ unsigned long long s_acc[MAXC][AQ];
+    __shared__ double s_tf[NT / 64][NF][65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ int s_tkey[NT / 64][64];
+    __shared__ int s_cnt;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ty0 = (tile / P.tiles_x) * SWEEP_TILE, tx0 = (tile % P.tiles_x) * SWEEP_TILE;
+    const int ty1 = min(ty0 + SWEEP_TILE, P.H), tx1 = min(tx0 + SWEEP_TILE, P.W);
+
+    for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+
+    // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
+    // candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H))
+    // that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel of slack covers float rounding of the binning.
+    {
+        int by_lo = (ty0 - 2 * P.sy - 2) / P.sy; if (ty0 - 2 * P.sy - 2 < 0) by_lo = 0;
+        int by_hi = (ty1 + 2 * P.sy + 1) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
+        int bx_lo = (tx0 - 2 * P.sx - 2) / P.sx; if (tx0 - 2 * P.sx - 2 < 0) bx_lo = 0;
+        int bx_hi = (tx1 + 2 * P.sx + 1) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
+        const int nbw = bx_hi - bx_lo + 1;
+        const int nbins = (by_hi - by_lo + 1) * nbw;
+        for (int bi = tid; bi < nbins; bi += NT) {
+            int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
+            while (cur >= 0) {
+                const int *irec = reinterpret_cast<const int *>(cent + (size_t)cur * RS);
+                const int y0 = irec[2], y1 = irec[3], x0 = irec[4], x1 = irec[5];
+                if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
+                    const int slot = atomicAdd(&s_cnt, 1);
+                    if (slot < MAXC) {
+                        const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
+                        float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
+                        dh[0] = src[0]; dh[1] = src[1];
+                        float4 *dc = reinterpret_cast<float4 *>(&s_col[slot][0]);
+#pragma unroll
+                        for (int q = 0; q < CP / 4; ++q) dc[q] = src[2 + q];
+                    }
+                }
+                cur = next[cur];
+            }
+        }
+    }
+    __syncthreads();
+    const int nc = s_cnt;
+    if (nc > MAXC) {   // wave-uniform (whole workgroup)
+        slow_tile<CP, MASKED, IGNORE_COLOR>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
+                                            start_label, fscale);
+        return;
+    }
+
+    // ---- 2. per wave: four 16x16 footprints ----------------------------------------------------------------------
+    const float w = P.spatial_w;
+    const int fy0 = ty0 + FB * wv;
+    for (int bxi = 0; bxi < SWEEP_TILE / FB; ++bxi) {
+        const int fx0 = tx0 + FB * bxi;
+        if (fy0 >= P.H || fx0 >= P.W) continue;   // wave-uniform
+        const int fy1 = min(fy0 + FB, P.H), fx1 = min(fx0 + FB, P.W);
+        const int x = fx0 + (lane & 15), yb = fy0 + PPT * (lane >> 4);
+        const float fx = (float)x;
+
+        float f[PPT][CP];
+        bool valid[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int y = yb + j;
+            bool v = (y < P.H) && (x < P.W);
+            const long long pix = P.pix_off + (long long)y * P.W + x;
+            if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
+            valid[j] = v;
+            if (v && (!IGNORE_COLOR || accum_color)) {
+                const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) {
+                    const float4 t = src[q];
+                    f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
+            }
+        }
+        float best_d[PPT];
+        int best_s[PPT], best_k[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) { best_d[j] = INFINITY; best_s[j] = -1; best_k[j] = 0x7fffffff; }
+
+        // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
+        // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
+        // operation is monotone, so lb <= spatial(pixel) <= d(pixel) for every pixel of the footprint.
+        unsigned lbv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = 64 * r + lane;
+            unsigned key = 0xffffffffu;
+            if (c < nc) {
+                const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
+                const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+                const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
+                const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
+                if (y0 < fy1 && y1 > fy0 && x0 < fx1 && x1 > fx0) {
+                    const float cy = h0.x, cx = h0.y;
+                    const float ry = (cy < (float)fy0) ? (float)fy0 : ((cy > (float)(fy1 - 1)) ? (float)(fy1 - 1) : cy);
+                    const float rx = (cx < (float)fx0) ? (float)fx0 : ((cx > (float)(fx1 - 1)) ? (float)(fx1 - 1) : cx);
+                    const float tyv = cy - ry, txv = cx - rx;
+                    const float lb = (tyv * tyv + txv * txv) * w;
+                    key = __float_as_uint(lb);      // lb >= 0: bit pattern order == value order; never 0xffffffff
+                }
+            }
+            lbv[r] = key;
+        }
+
+        // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
+        unsigned maxbest = 0x7f800000u;   // +inf
+        for (;;) {
+            const unsigned mn = wave_umin(min(lbv[0], lbv[1]));
+            if (mn == 0xffffffffu || mn > maxbest) break;   // equality must still be visited: it can tie on k
+            int c;
+            {
+                const unsigned long long b0 = __ballot(lbv[0] == mn);
+                if (b0) { c = __ffsll((long long)b0) - 1; if (lane == c) lbv[0] = 0xffffffffu; }
+                else {
+                    const unsigned long long b1 = __ballot(lbv[1] == mn);
+                    c = __ffsll((long long)b1) - 1;
+                    if (lane == c) lbv[1] = 0xffffffffu;
+                    c += 64;
+                }
+            }
+            const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
+            const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+            const float cy = h0.x, cx = h0.y;
+            const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
+            const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
+            const int kk = __float_as_int(h1.z);
+            const bool inx = (x >= x0) && (x < x1);
+            const float tx = cx - fx;
+            const float dx2 = tx * tx;
+            bool need[PPT];
+            float dsp[PPT];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int y = yb + j;
+                const float tyv = cy - (float)y;
+                const float dy2 = tyv * tyv;
+                dsp[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
+                // colour >= 0 and float add is monotone, so d >= dsp: a candidate whose spatial part already exceeds
+                // the best distance cannot win (equality could still tie on k)
+                need[j] = valid[j] && inx && (y >= y0) && (y < y1) && !(dsp[j] > best_d[j]);
+                any |= need[j];
+            }
+            if (any) {
+                float col[CP];
+                if (!IGNORE_COLOR) {
+#pragma unroll
+                    for (int q = 0; q < CP / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
+                        col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    float d = dsp[j];
+                    if (!IGNORE_COLOR) {
+                        float dc = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) {
+                            const float t = f[j][ch] - col[ch];
+                            dc += t * t;
+                        }
+                        d += dc;
+                    }
+                    // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k)
+                    const bool better = need[j] && (d < best_d[j] || (d == best_d[j] && kk < best_k[j]));
+                    best_d[j] = better ? d : best_d[j];
+                    best_s[j] = better ? c : best_s[j];
+                    best_k[j] = better ? kk : best_k[j];
+                }
+            }
+            // largest best distance in the wave (+inf while a valid pixel is unassigned)
+            float lm = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) lm = valid[j] ? fmaxf(lm, best_d[j]) : lm;
+            maxbest = wave_umax(__float_as_uint(lm));
+        }
+
+        // ---- labels ---------------------------------------------------------------------------------------------------
+        int pk[PPT];   // accumulation key: LDS slot, or -1
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int y = yb + j;
+            const bool inimg = (y < P.H) && (x < P.W);
+            const long long pix = P.pix_off + (long long)y * P.W + x;
+            pk[j] = (valid[j] && best_s[j] >= 0) ? best_s[j] : -1;
+            if (!inimg) continue;
+            if (valid[j] && best_s[j] < 0) {
+                // no window reaches this pixel: `nearest` keeps the previous sweep's value (it is only initialised
+                // once, before the loop) and the pixel is accumulated under it
+                const int prev = labels[pix];
+                if (prev >= start_label && accumulate) {
+                    double one[CP];
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) one[ch] = (double)f[j][ch];
+                    global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, 1u, (unsigned)y,
+                                          (unsigned long long)x, one, fscale);
+                }
+            } else {
+                labels[pix] = (best_s[j] >= 0) ? (best_k[j] - P.cent_off + start_label) : (start_label - 1);
+            }
+        }
+        if (!accumulate) continue;
+
+        // ---- 3. fused centroid update ------------------------------------------------------------------------------------
+        // per-lane runs of equal slot over the strip; the first run goes through the transposed fold, later runs
+        // (a strip crossing a segment boundary) go straight to the LDS accumulators
+        int key0 = -1;
+        double p_n = 0.0, p_y = 0.0, pf[CP];
+#pragma unroll
+        for (int ch = 0; ch < CP; ++ch) pf[ch] = 0.0;
+        {
+            int rkey = -1, nruns = 0;
+            unsigned rn = 0, ry = 0;
+            double rf[CP];
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+            auto close_run = [&]() {
+                if (rkey < 0) return;
+                if (nruns == 0) {
+                    key0 = rkey; p_n = (double)rn; p_y = (double)ry;
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) pf[ch] = rf[ch];
+                } else {
+                    if (accum_color) {
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][ch], to_fixed(rf[ch], fscale));
+                    }
+                    atomicAdd(&s_acc[rkey][CP], (unsigned long long)rn | ((unsigned long long)ry << 32));
+                    atomicAdd(&s_acc[rkey][CP + 1], (unsigned long long)rn * (unsigned long long)x);
+                }
+                ++nruns;
+            };
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                if (pk[j] != rkey) {
+                    close_run();
+                    rkey = pk[j]; rn = 0; ry = 0;
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+                }
+                if (pk[j] >= 0) {
+                    rn += 1; ry += (unsigned)(yb + j);
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
+                }
+            }
+            close_run();
+        }
+        // transpose: lane writes its partial, then lane (fld, g) folds the 16 strips 16g .. 16g+15 of field fld
+        s_tkey[wv][lane] = key0;
+        if (accum_color) {
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) s_tf[wv][ch][lane] = pf[ch];
+        }
+        s_tf[wv][CP][lane] = p_n;
+        s_tf[wv][CP + 1][lane] = p_y;
+        s_tf[wv][CP + 2][lane] = p_n * (double)x;
+        wave_lds_sync();
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int fld = 16 * pass + (lane & 15), g = lane >> 4;
+            if (fld < NF && (accum_color || fld >= CP)) {
+                int cur = -1;
+                double sum = 0.0;
+                auto emit = [&]() {
+                    if (cur < 0) return;
+                    if (fld < CP) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
+                    else if (fld == CP) atomicAdd(&s_acc[cur][CP], (unsigned long long)(unsigned)sum);              // n
+                    else if (fld == CP + 1) atomicAdd(&s_acc[cur][CP], (unsigned long long)(unsigned)sum << 32);    // sum_y
+                    else atomicAdd(&s_acc[cur][CP + 1], (unsigned long long)sum);                                     // sum_x
+                };
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int src = 16 * g + i;
+                    const int key = s_tkey[wv][src];
+                    const double v = s_tf[wv][fld][src];
+                    if (key != cur) { emit(); cur = key; sum = 0.0; }
+                    sum += v;
+                }
+                emit();
+            }
+        }
+        wave_lds_sync();   // the scratch is rewritten by the next footprint
+    }
+    if (!accumulate) return;
+    __syncthreads();
+    // ---- LDS accumulators -> global records: consecutive lanes write consecutive qwords of one 128-B record -----------
+    for (int i = tid; i < nc * AQ; i += NT) {
+        const int slot = i / AQ, q = i - slot * AQ;
+        if ((s_acc[slot][CP] & 0xffffffffull) == 0ull) continue;   // n == 0: nothing landed on this centroid
+        const int k = __float_as_int(s_hdr[slot][6]);
+        atomicAdd(&acc[(size_t)k * RQ + q], s_acc[slot][q]);
+    }
+}
+
+template <int CP>
+static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color) {
+    dim3 grid(b.total_tiles, b.nprob);
+    static const int ablate = getenv("OBIA_ABLATE") ? atoi(getenv("OBIA_ABLATE")) : 0;   // timing experiments only
+    if (ablate & 1) accumulate = 0;
+    const int RQ = acc_record_qwords(CP);
+#define LAUNCH_ASSIGN(M, I)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
+                       accum_color, b.start_label, b.fscale)
+    if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
+    else LAUNCH_ASSIGN(false, false);
+#undef LAUNCH_ASSIGN
+}
+
+__global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
+    // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
+    {
+        long long n = b.total_pix;
+        int blocks = cdiv(n, 256 * 8);
+        if (blocks > 65535) blocks = 65535;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
+    }
+    if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
+    const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
+    const int RQ = acc_record_qwords(b.CP);
+    bool first = true;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
+        const bool last_pass = (pass == passes - 1);
+        for (int it = 0; it < b.max_iter; ++it) {
+            OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));
+            hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
+                               b.d_cent_prob, b.total_cent, b.CP, RQ, first ? 1 : 0, b.d_seed, b.d_acc, 1.0 / b.fscale,
+                               b.d_cent, b.d_head, b.d_next);
+            first = false;
+            // the update after the very last sweep is never read: skip its accumulation
+            const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
+            const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
+            {
+                ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
+                if (!ignore_color) ctx->timing.assign_px += (double)b.total_pix;
+                switch (b.CP) {
+                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color); break;
+                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color); break;
+                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color); break;
+                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color); break;
+                    default: set_error("bad CP"); return OBIA_E_INVALID;
+                }
+            }
+        }
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    return OBIA_OK;
+}
+
+}  // namespace obia
