@@ -263,11 +263,14 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     }
     float maxabs; unsigned mb = host[nkeys + np]; memcpy(&maxabs, &mb, 4);
     if (!(maxabs <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
-    // fixed-point scale for the colour sums: |feature| * maxcount * 2^s < 2^62
+    // fixed-point scale for the colour sums: totals |feature| * maxcount * 2^s < 2^62, and every partial that is
+    // converted (at most one 64x64 tile of pixels) stays below 2^50 (to_fixed in slic_sweep.hip needs < 2^51)
     long long maxcount = 1;
     for (auto &w : b.windows) { long long n = (long long)w.h * w.w; if (n > maxcount) maxcount = n; }
     double bound = ((double)maxabs + 1e-30) * (double)maxcount;
     int s = 62 - (int)std::ceil(std::log2(bound + 1.0));
+    const int s2 = 50 - (int)std::ceil(std::log2(((double)maxabs + 1e-30) * 4096.0 + 1.0));
+    if (s2 < s) s = s2;
     if (s > 40) s = 40;
     if (s < -60) s = -60;
     b.fscale = std::ldexp(1.0, s);

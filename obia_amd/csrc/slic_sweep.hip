@@ -92,8 +92,13 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
 }
 
+// double -> 64-bit fixed point, round to nearest even.  |v * fscale| < 2^51 (the scale is chosen for that in
+// slic_prepare_features), so adding 1.5 * 2^52 leaves the integer in the low mantissa bits: one FMA and one
+// 64-bit subtract instead of the ~10-instruction conversion sequence.
 __device__ __forceinline__ unsigned long long to_fixed(double v, double fscale) {
-    return (unsigned long long)__double2ll_rn(v * fscale);
+    const double magic = 6755399441055744.0;   // 2^52 + 2^51
+    const double t = __fma_rn(v, fscale, magic);
+    return (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(magic));
 }
 
 // ---- wave-wide reductions on DPP (no LDS traffic) ---------------------------------------------------
@@ -121,12 +126,13 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
     return min(min(a, b), min(c, d));
 }
 
-// LDS written by some lanes of a wave, read by others of the same wave: the LDS pipe is in order per
-// wave, so a compiler-level fence is all that is needed.
+// LDS written by some lanes of a wave and read by other lanes of the same wave: the LDS pipe executes a
+// wave's instructions in order, so only the COMPILER must be kept from moving accesses across this point.
+// (A workgroup-scope fence would also emit s_waitcnt vmcnt(0) and stall on the label stores in flight.)
 __device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("" ::: "memory");
 }
 
 template <int CP>
@@ -210,14 +216,15 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     const int tile = blockIdx.x;
     if (tile >= P.tiles_x * P.tiles_y) return;
     constexpr int RS = CENT_REC + CP;
-    constexpr int AQ = CP + 2;                  // qwords of an LDS accumulator: colours, n|sum_y<<32, sum_x
-    constexpr int NF = CP + 3;                  // transposed fields: colours, n, sum_y, sum_x (as doubles)
-    constexpr int NPASS = (NF + 15) / 16;
+    constexpr int AQ = CP + 1;                  // qwords of an LDS accumulator: colours, then one packed word
+                                                //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 64x64 tile: n <= 4096,
+                                                //   sums <= 4096 * 63 < 2^18: no field can carry into the next)
+    constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
     __shared__ __attribute__((aligned(16))) float s_col[MAXC][CP];
     __shared__ unsigned long long s_acc[MAXC][AQ];
-    __shared__ double s_tf[NT / 64][NF][65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ double s_tf[NT / 64][CP][65];    // 65: row stride that keeps the transposed reads conflict-free
     __shared__ int s_tkey[NT / 64][64];
     __shared__ int s_cnt;
 
@@ -270,11 +277,15 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     // ---- 2. per wave: four 16x16 footprints ----------------------------------------------------------------------
     const float w = P.spatial_w;
     const int fy0 = ty0 + FB * wv;
-    for (int bxi = 0; bxi < SWEEP_TILE / FB; ++bxi) {
+    const bool wave_active = fy0 < P.H;   // a wave below the bottom edge only helps with the final flush
+    const int fy1 = min(fy0 + FB, P.H);
+    const int yb = fy0 + PPT * (lane >> 4);
+    const bool want_feat = !IGNORE_COLOR || accum_color;
+    for (int bxi = 0; wave_active && bxi < SWEEP_TILE / FB; ++bxi) {
         const int fx0 = tx0 + FB * bxi;
-        if (fy0 >= P.H || fx0 >= P.W) continue;   // wave-uniform
-        const int fy1 = min(fy0 + FB, P.H), fx1 = min(fx0 + FB, P.W);
-        const int x = fx0 + (lane & 15), yb = fy0 + PPT * (lane >> 4);
+        if (fx0 >= P.W) break;   // wave-uniform
+        const int fx1 = min(fx0 + FB, P.W);
+        const int x = fx0 + (lane & 15);
         const float fx = (float)x;
 
         float f[PPT][CP];
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             const long long pix = P.pix_off + (long long)y * P.W + x;
             if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
             valid[j] = v;
-            if (v && (!IGNORE_COLOR || accum_color)) {
+            if (v && want_feat) {
                 const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
 #pragma unroll
                 for (int q = 0; q < CP / 4; ++q) {
@@ -298,10 +309,11 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
                 for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
             }
         }
-        float best_d[PPT];
-        int best_s[PPT], best_k[PPT];
+        // best_d of an invalid pixel is -inf: nothing is ever smaller, so the visits need no `valid` test
+        float best_d[PPT], fyv[PPT];
+        int best_s[PPT];
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) { best_d[j] = INFINITY; best_s[j] = -1; best_k[j] = 0x7fffffff; }
+        for (int j = 0; j < PPT; ++j) { best_d[j] = valid[j] ? INFINITY : -INFINITY; best_s[j] = -1; fyv[j] = (float)(yb + j); }
 
         // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
         // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
@@ -344,63 +356,80 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
                     c += 64;
                 }
             }
+            // the candidate's header is wave-uniform: keep it in scalar registers
             const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
             const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
-            const float cy = h0.x, cx = h0.y;
-            const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
-            const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
-            const int kk = __float_as_int(h1.z);
-            const bool inx = (x >= x0) && (x < x1);
+            const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h0.x)));
+            const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h0.y)));
+            const int y0 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.z)), y1 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.w));
+            const int x0 = __builtin_amdgcn_readfirstlane(__float_as_int(h1.x)), x1 = __builtin_amdgcn_readfirstlane(__float_as_int(h1.y));
+            const int kk = __builtin_amdgcn_readfirstlane(__float_as_int(h1.z));
+            // a window that covers the whole footprint (the common case: windows are ~4S wide) needs no per-pixel test
+            const bool covers = (y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1);
             const float tx = cx - fx;
             const float dx2 = tx * tx;
-            bool need[PPT];
-            float dsp[PPT];
+            const bool inx = covers || ((x >= x0) && (x < x1));
+            float dv[PPT];
+            bool cand[PPT];     // this candidate may still win or tie this pixel
             bool any = false;
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
-                const int y = yb + j;
-                const float tyv = cy - (float)y;
+                const float tyv = cy - fyv[j];
                 const float dy2 = tyv * tyv;
-                dsp[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
-                // colour >= 0 and float add is monotone, so d >= dsp: a candidate whose spatial part already exceeds
-                // the best distance cannot win (equality could still tie on k)
-                need[j] = valid[j] && inx && (y >= y0) && (y < y1) && !(dsp[j] > best_d[j]);
-                any |= need[j];
+                dv[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
+                // colour >= 0 and float add is monotone, so d >= spatial: a candidate whose spatial part already
+                // exceeds the best distance cannot win (equality could still tie on k)
+                bool cnd = !(dv[j] > best_d[j]);
+                if (!covers) cnd = cnd && inx && ((unsigned)(yb + j - y0) < (unsigned)(y1 - y0));
+                cand[j] = cnd;
+                any |= cnd;
             }
             if (any) {
-                float col[CP];
                 if (!IGNORE_COLOR) {
+                    float col[CP];
 #pragma unroll
                     for (int q = 0; q < CP / 4; ++q) {
                         const float4 t = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
                         col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    float d = dsp[j];
-                    if (!IGNORE_COLOR) {
+                    for (int j = 0; j < PPT; ++j) {
                         float dc = 0.0f;
 #pragma unroll
                         for (int ch = 0; ch < CP; ++ch) {
                             const float t = f[j][ch] - col[ch];
                             dc += t * t;
                         }
-                        d += dc;
+                        dv[j] += dc;
                     }
-                    // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k)
-                    const bool better = need[j] && (d < best_d[j] || (d == best_d[j] && kk < best_k[j]));
-                    best_d[j] = better ? d : best_d[j];
-                    best_s[j] = better ? c : best_s[j];
-                    best_k[j] = better ? kk : best_k[j];
+                }
+                // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k).  Exact ties are
+                // rare: the strict comparison is the fast path, ties are resolved on k only when one occurred.
+                bool tie = false;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const bool lt = cand[j] && (dv[j] < best_d[j]);
+                    tie |= cand[j] && (dv[j] == best_d[j]);
+                    best_d[j] = lt ? dv[j] : best_d[j];
+                    best_s[j] = lt ? c : best_s[j];
+                }
+                if (tie) {
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j) {
+                        if (cand[j] && dv[j] == best_d[j] && best_s[j] != c && dv[j] < INFINITY) {   // `inf > inf` never assigns
+                            const int bk = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : 0x7fffffff;
+                            if (kk < bk) best_s[j] = c;
+                        }
+                    }
                 }
             }
-            // largest best distance in the wave (+inf while a valid pixel is unassigned)
-            float lm = 0.0f;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) lm = valid[j] ? fmaxf(lm, best_d[j]) : lm;
+            // largest best distance in the wave (+inf while a valid pixel is unassigned; invalid pixels hold -inf)
+            const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
             maxbest = wave_umax(__float_as_uint(lm));
         }
+        int best_k[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) best_k[j] = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : -1;
 
         // ---- labels ---------------------------------------------------------------------------------------------------
         int pk[PPT];   // accumulation key: LDS slot, or -1
@@ -429,13 +458,13 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
         if (!accumulate) continue;
 
         // ---- 3. fused centroid update ------------------------------------------------------------------------------------
-        // per-lane runs of equal slot over the strip; the first run goes through the transposed fold, later runs
-        // (a strip crossing a segment boundary) go straight to the LDS accumulators
-        int key0 = -1;
-        double p_n = 0.0, p_y = 0.0, pf[CP];
-#pragma unroll
-        for (int ch = 0; ch < CP; ++ch) pf[ch] = 0.0;
+        // Integer part (n, sum_y, sum_x): one packed 64-bit LDS atomic per run, tile-relative coordinates.
+        // Colour part: per-lane runs of equal slot over the strip, summed in double (exact for 4 floats); the FIRST run
+        // of every lane goes through the transposed fold below, later runs (a strip crossing a segment boundary) go
+        // straight to the LDS accumulators.
+        if (accum_color) s_tkey[wv][lane] = -1;
         {
+            const unsigned long long xrel = (unsigned long long)(x - tx0);
             int rkey = -1, nruns = 0;
             unsigned rn = 0, ry = 0;
             double rf[CP];
@@ -443,17 +472,16 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
             auto close_run = [&]() {
                 if (rkey < 0) return;
-                if (nruns == 0) {
-                    key0 = rkey; p_n = (double)rn; p_y = (double)ry;
+                atomicAdd(&s_acc[rkey][CP], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
+                if (accum_color) {
+                    if (nruns == 0) {   // the lane's slot in the transposed scratch
+                        s_tkey[wv][lane] = rkey;
 #pragma unroll
-                    for (int ch = 0; ch < CP; ++ch) pf[ch] = rf[ch];
-                } else {
-                    if (accum_color) {
+                        for (int ch = 0; ch < CP; ++ch) s_tf[wv][ch][lane] = rf[ch];
+                    } else {
 #pragma unroll
                         for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][ch], to_fixed(rf[ch], fscale));
                     }
-                    atomicAdd(&s_acc[rkey][CP], (unsigned long long)rn | ((unsigned long long)ry << 32));
-                    atomicAdd(&s_acc[rkey][CP + 1], (unsigned long long)rn * (unsigned long long)x);
                 }
                 ++nruns;
             };
@@ -466,45 +494,36 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
                     for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
                 }
                 if (pk[j] >= 0) {
-                    rn += 1; ry += (unsigned)(yb + j);
+                    rn += 1; ry += (unsigned)(yb + j - ty0);
+                    if (accum_color) {
 #pragma unroll
-                    for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
+                        for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
+                    }
                 }
             }
             close_run();
         }
-        // transpose: lane writes its partial, then lane (fld, g) folds the 16 strips 16g .. 16g+15 of field fld
-        s_tkey[wv][lane] = key0;
-        if (accum_color) {
-#pragma unroll
-            for (int ch = 0; ch < CP; ++ch) s_tf[wv][ch][lane] = pf[ch];
-        }
-        s_tf[wv][CP][lane] = p_n;
-        s_tf[wv][CP + 1][lane] = p_y;
-        s_tf[wv][CP + 2][lane] = p_n * (double)x;
+        if (!accum_color) continue;   // wave-uniform: spatial-only pre-pass sweeps fold no colours
+        // transposed fold: lane (fld, g) folds the 8 strips 8g .. 8g+7 of colour field fld
         wave_lds_sync();
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            const int fld = 16 * pass + (lane & 15), g = lane >> 4;
-            if (fld < NF && (accum_color || fld >= CP)) {
+            const int fld = 8 * pass + (lane & 7), g = lane >> 3;
+            if (fld < CP) {
                 int cur = -1;
                 double sum = 0.0;
-                auto emit = [&]() {
-                    if (cur < 0) return;
-                    if (fld < CP) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
-                    else if (fld == CP) atomicAdd(&s_acc[cur][CP], (unsigned long long)(unsigned)sum);              // n
-                    else if (fld == CP + 1) atomicAdd(&s_acc[cur][CP], (unsigned long long)(unsigned)sum << 32);    // sum_y
-                    else atomicAdd(&s_acc[cur][CP + 1], (unsigned long long)sum);                                     // sum_x
-                };
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const int src = 16 * g + i;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int src = 8 * g + i;
                     const int key = s_tkey[wv][src];
-                    const double v = s_tf[wv][fld][src];
-                    if (key != cur) { emit(); cur = key; sum = 0.0; }
+                    const double v = key >= 0 ? s_tf[wv][fld][src] : 0.0;   // strips without a run left stale data
+                    if (key != cur) {
+                        if (cur >= 0) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
+                        cur = key; sum = 0.0;
+                    }
                     sum += v;
                 }
-                emit();
+                if (cur >= 0) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
             }
         }
         wave_lds_sync();   // the scratch is rewritten by the next footprint
@@ -512,11 +531,18 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     if (!accumulate) return;
     __syncthreads();
     // ---- LDS accumulators -> global records: consecutive lanes write consecutive qwords of one 128-B record -----------
-    for (int i = tid; i < nc * AQ; i += NT) {
-        const int slot = i / AQ, q = i - slot * AQ;
-        if ((s_acc[slot][CP] & 0xffffffffull) == 0ull) continue;   // n == 0: nothing landed on this centroid
+    constexpr int GQ = CP + 2;   // global record: colours, n | sum_y << 32, sum_x
+    for (int i = tid; i < nc * GQ; i += NT) {
+        const int slot = i / GQ, q = i - slot * GQ;
+        const unsigned long long pw = s_acc[slot][CP];
+        const unsigned long long n = pw & 0xffffull;
+        if (n == 0ull) continue;   // nothing landed on this centroid
         const int k = __float_as_int(s_hdr[slot][6]);
-        atomicAdd(&acc[(size_t)k * RQ + q], s_acc[slot][q]);
+        unsigned long long v;
+        if (q < CP) { if (!accum_color) continue; v = s_acc[slot][q]; }
+        else if (q == CP) v = n | ((((pw >> 16) & 0xffffffull) + n * (unsigned long long)ty0) << 32);
+        else v = (pw >> 40) + n * (unsigned long long)tx0;
+        atomicAdd(&acc[(size_t)k * RQ + q], v);
     }
 }
 
