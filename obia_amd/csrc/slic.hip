@@ -78,8 +78,10 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 constexpr int FP_NT = 256;
 
-// K0a: per-band min/max of each problem window.  Threads own a fixed band (stride is a multiple of
-// C), elements of a row are read as coalesced dwords.  grid = (blocks, nprob).
+// K0a: per-band min/max of each problem window.  A row of a band-interleaved window is a flat run of
+// w*C floats; lanes read it as coalesced float4 (C % 4 == 0) or dwords, and the thread count in use is a
+// multiple of the band period so that every thread owns a fixed band (group).  grid = (blocks, nprob).
+template <int VEC>
 __global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restrict__ src, int Ws, int C,
                                                             const SrcWindow *__restrict__ wins,
                                                             unsigned *__restrict__ keys /*[nprob][C][2]*/,
@@ -87,28 +89,40 @@ __global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restr
     __shared__ unsigned s_mn[32], s_mx[32];
     const int p = blockIdx.y;
     const SrcWindow wdw = wins[p];
-    const int active = (FP_NT / C) * C;
+    const int period = C / VEC;                 // threads per pixel
+    const int active = (FP_NT / period) * period;
     const int tid = threadIdx.x;
     if (tid < 32) { s_mn[tid] = 0xffffffffu; s_mx[tid] = 0u; }
     __syncthreads();
-    float lo = INFINITY, hi = -INFINITY;
+    float lo[VEC], hi[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { lo[v] = INFINITY; hi[v] = -INFINITY; }
     bool bad = false;
     if (tid < active) {
-        const long long row_elems = (long long)wdw.w * C;
+        const long long row_vecs = (long long)wdw.w * period;
         for (int y = blockIdx.x; y < wdw.h; y += gridDim.x) {
             const float *row = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0) * C;
-            for (long long e = tid; e < row_elems; e += active) {
-                float v = row[e];
-                bad |= !(fabsf(v) <= 3.4028234e38f);
-                lo = fminf(lo, v);
-                hi = fmaxf(hi, v);
+            for (long long e = tid; e < row_vecs; e += active) {
+                float v[VEC];
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(row + 4 * e);
+                    v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+                } else v[0] = row[e];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    bad |= !(fabsf(v[q]) <= 3.4028234e38f);
+                    lo[q] = fminf(lo[q], v[q]);
+                    hi[q] = fmaxf(hi[q], v[q]);
+                }
             }
         }
-        const int band = tid % C;
-        if (lo <= hi) {
-            atomicMin(&s_mn[band], f2key(lo));
-            atomicMax(&s_mx[band], f2key(hi));
-        }
+        const int band0 = (tid % period) * VEC;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+            if (lo[q] <= hi[q]) {
+                atomicMin(&s_mn[band0 + q], f2key(lo[q]));
+                atomicMax(&s_mx[band0 + q], f2key(hi[q]));
+            }
         if (bad) atomicOr(&nonfinite[p], 1);
     }
     __syncthreads();
@@ -146,7 +160,8 @@ __device__ __forceinline__ void rgb2lab_f32(float r, float g, float b, float &L,
 
 // K0b: features = [normalize_band] -> [rgb2lab] -> * float32(1/compactness), written to the dense
 // per-problem buffer padded to CP channels (padding is 0: `t = 0 - 0; dc += t*t` leaves every
-// distance bit-identical).  Also reduces max|feature| for the fixed-point scale.
+// distance bit-identical).  Also reduces max|feature| for the fixed-point scale.  Per-band min and
+// (max - min) are hoisted into registers; C % 4 == 0 rasters are read as float4.
 template <int CP>
 __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__ src, int Ws, int C,
                                                        const SrcWindow *__restrict__ wins,
@@ -156,26 +171,43 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     const int p = blockIdx.y;
     const SrcWindow wdw = wins[p];
     const long long npix = (long long)wdw.h * wdw.w;
+    float bmn[CP], bden[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        bmn[c] = 0.0f; bden[c] = 1.0f;
+        if (normalize && c < C) {
+            const float mn = key2f(keys[((long long)p * C + c) * 2 + 0]);
+            const float mx = key2f(keys[((long long)p * C + c) * 2 + 1]);
+            bmn[c] = mn; bden[c] = mx - mn;     // (band - min) / (max - min), segment_boundaries.py:16
+        }
+    }
+    const bool vec = (C == CP);                 // C % 4 == 0: aligned float4 reads
     float local_max = 0.0f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
          i += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(i / wdw.w), x = (int)(i % wdw.w);
         const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
         float v[CP];
+        if (vec) {
 #pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            float t = 0.0f;
-            if (c < C) {
-                t = px[c];
-                if (normalize) {
-                    const float mn = key2f(keys[((long long)p * C + c) * 2 + 0]);
-                    const float mx = key2f(keys[((long long)p * C + c) * 2 + 1]);
-                    t = (t - mn) / (mx - mn);
-                }
-                if (!(fabsf(t) <= 3.0e38f)) t = 0.0f;   // constant / non-finite band: the problem is rejected on the host
-
+            for (int q = 0; q < CP / 4; ++q) {
+                const float4 t = reinterpret_cast<const float4 *>(px)[q];
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
             }
-            v[c] = t;
+        } else {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) v[c] = (c < C) ? px[c] : 0.0f;
+        }
+        if (normalize) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                float t = (v[c] - bmn[c]) / bden[c];
+                if (!(fabsf(t) <= 3.0e38f)) t = 0.0f;   // constant / non-finite band: the problem is rejected on the host
+                v[c] = t;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) if (!(fabsf(v[c]) <= 3.0e38f)) v[c] = 0.0f;
         }
         if (to_lab) {
             float L, A, B;
@@ -196,7 +228,6 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
     if ((threadIdx.x & 63) == 0) atomicMax(maxabs_bits, __float_as_uint(local_max));
 }
-
 
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
                           int to_lab, float ratio, std::vector<int> *skip) {
@@ -219,8 +250,13 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; long long n = (long long)w.h * w.w; if (n > maxpix) maxpix = n; }
     if (normalize) {
         int gx = maxh < 2048 ? maxh : 2048;
-        hipLaunchKernelGGL(band_minmax_kernel, dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C, b.d_windows, d_keys,
-                           (int *)d_nonfinite);
+        // float4 reads need 16-byte aligned rows: C % 4 == 0 and an aligned base pointer
+        if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<4>), dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C,
+                               b.d_windows, d_keys, (int *)d_nonfinite);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<1>), dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C,
+                               b.d_windows, d_keys, (int *)d_nonfinite);
     }
     {
         int blocks = cdiv(maxpix, 256 * 4);
@@ -355,21 +391,36 @@ __global__ __launch_bounds__(256) void seed_masked_kernel(const SeedGrid *__rest
     if (tid == 0) K_out[p] = K;
 }
 
-// valid-pixel count per problem (mask.sum(), tiling.py:133 / slic_superpixels.py:322)
+// valid-pixel count per problem (mask.sum(), tiling.py:133 / slic_superpixels.py:322); 16 mask bytes per load
 __global__ __launch_bounds__(256) void count_valid_kernel(const SlicProblem *__restrict__ probs,
                                                           const uint8_t *__restrict__ mask, int *__restrict__ out) {
     const int p = blockIdx.y;
     const SlicProblem P = probs[p];
     const long long npix = (long long)P.H * P.W;
+    const uint8_t *m = mask + P.pix_off;
     int c = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x)
-        c += mask[P.pix_off + i] != 0;
+    const long long head = ((16 - (reinterpret_cast<uintptr_t>(m) & 15)) & 15);
+    const long long h0 = head < npix ? head : npix;
+    const long long nvec = (npix - h0) / 16;
+    const uint4 *mv = reinterpret_cast<const uint4 *>(m + h0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 t = mv[i];
+        const unsigned wds[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned nz = wds[q] | (wds[q] >> 4);
+            nz |= nz >> 2; nz |= nz >> 1;
+            c += __popc(nz & 0x01010101u);
+        }
+    }
+    if (blockIdx.x == 0) {   // unaligned head and tail bytes
+        for (long long i = threadIdx.x; i < h0; i += blockDim.x) c += m[i] != 0;
+        for (long long i = h0 + nvec * 16 + threadIdx.x; i < npix; i += blockDim.x) c += m[i] != 0;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&out[p], c);
 }
-
-
 
 int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
     const int np = b.nprob;
@@ -384,7 +435,7 @@ int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
         OBIA_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * np, ctx->stream));
         long long maxpix = 1;
         for (auto &P : b.probs) { long long n = (long long)P.H * P.W; if (n > maxpix) maxpix = n; }
-        int blocks = cdiv(maxpix, 256 * 16);
+        int blocks = cdiv(maxpix, 256 * 16 * 4);
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(count_valid_kernel, dim3(blocks, np), dim3(256), 0, ctx->stream, b.d_probs, b.d_mask, d_cnt);
         OBIA_TRY(read_back(ctx, nvalid.data(), d_cnt, sizeof(int) * np));

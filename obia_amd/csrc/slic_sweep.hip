@@ -30,6 +30,18 @@
 
 namespace obia {
 
+#ifdef OBIA_STAMP
+// Diagnostic build only (make STAMP=1): per-phase wave-cycle sums, written to a buffer no other code reads.
+__device__ unsigned long long g_stamp[16];
+#define STAMP_DECL unsigned long long st_t = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) { const unsigned long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 8; ++st_i) atomicAdd(&g_stamp[st_i], st_acc[st_i]); atomicAdd(&g_stamp[15], 1ull); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
 constexpr int PPT = 4;          // pixels per lane (vertical strip)
@@ -232,9 +244,44 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     const int ty0 = (tile / P.tiles_x) * SWEEP_TILE, tx0 = (tile % P.tiles_x) * SWEEP_TILE;
     const int ty1 = min(ty0 + SWEEP_TILE, P.H), tx1 = min(tx0 + SWEEP_TILE, P.W);
 
+    STAMP_DECL
     for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
+
+    // ---- wave geometry; the features of the wave's FIRST footprint are requested before staging, so their HBM
+    // latency overlaps the dependent bin -> record loads of the staging phase ---------------------------------------
+    const float w = P.spatial_w;
+    const int fy0 = ty0 + FB * wv;
+    const bool wave_active = fy0 < P.H;   // a wave below the bottom edge only helps with the final flush
+    const int fy1 = min(fy0 + FB, P.H);
+    const int yb = fy0 + PPT * (lane >> 4);
+    const bool want_feat = !IGNORE_COLOR || accum_color;
+    float f[PPT][CP];
+    bool valid[PPT];
+    auto fetch = [&](int fx0) {
+        const int xx = fx0 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int y = yb + j;
+            bool v = (y < P.H) && (xx < P.W);
+            const long long pix = P.pix_off + (long long)y * P.W + xx;
+            if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
+            valid[j] = v;
+            if (v && want_feat) {
+                const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) {
+                    const float4 t = src[q];
+                    f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
+            }
+        }
+    };
+    if (wave_active) fetch(tx0);
 
     // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
     // candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H))
@@ -267,6 +314,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
         }
     }
     __syncthreads();
+    STAMP(0)   // staging
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
         slow_tile<CP, MASKED, IGNORE_COLOR>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
@@ -275,40 +323,13 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     }
 
     // ---- 2. per wave: four 16x16 footprints ----------------------------------------------------------------------
-    const float w = P.spatial_w;
-    const int fy0 = ty0 + FB * wv;
-    const bool wave_active = fy0 < P.H;   // a wave below the bottom edge only helps with the final flush
-    const int fy1 = min(fy0 + FB, P.H);
-    const int yb = fy0 + PPT * (lane >> 4);
-    const bool want_feat = !IGNORE_COLOR || accum_color;
     for (int bxi = 0; wave_active && bxi < SWEEP_TILE / FB; ++bxi) {
         const int fx0 = tx0 + FB * bxi;
         if (fx0 >= P.W) break;   // wave-uniform
         const int fx1 = min(fx0 + FB, P.W);
         const int x = fx0 + (lane & 15);
         const float fx = (float)x;
-
-        float f[PPT][CP];
-        bool valid[PPT];
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int y = yb + j;
-            bool v = (y < P.H) && (x < P.W);
-            const long long pix = P.pix_off + (long long)y * P.W + x;
-            if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
-            valid[j] = v;
-            if (v && want_feat) {
-                const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
-#pragma unroll
-                for (int q = 0; q < CP / 4; ++q) {
-                    const float4 t = src[q];
-                    f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
-            }
-        }
+        if (bxi > 0) fetch(fx0);
         // best_d of an invalid pixel is -inf: nothing is ever smaller, so the visits need no `valid` test
         float best_d[PPT], fyv[PPT];
         int best_s[PPT];
@@ -340,6 +361,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             lbv[r] = key;
         }
 
+        STAMP(2)   // scoring
         // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
         unsigned maxbest = 0x7f800000u;   // +inf
         for (;;) {
@@ -427,6 +449,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
             maxbest = wave_umax(__float_as_uint(lm));
         }
+        STAMP(3)   // visits
         int best_k[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) best_k[j] = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : -1;
@@ -455,6 +478,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
                 labels[pix] = (best_s[j] >= 0) ? (best_k[j] - P.cent_off + start_label) : (start_label - 1);
             }
         }
+        STAMP(4)   // labels
         if (!accumulate) continue;
 
         // ---- 3. fused centroid update ------------------------------------------------------------------------------------
@@ -503,6 +527,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             }
             close_run();
         }
+        STAMP(5)   // run merge
         if (!accum_color) continue;   // wave-uniform: spatial-only pre-pass sweeps fold no colours
         // transposed fold: lane (fld, g) folds the 8 strips 8g .. 8g+7 of colour field fld
         wave_lds_sync();
@@ -527,8 +552,9 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             }
         }
         wave_lds_sync();   // the scratch is rewritten by the next footprint
+        STAMP(6)   // fold
     }
-    if (!accumulate) return;
+    if (!accumulate) { STAMP_FLUSH return; }
     __syncthreads();
     // ---- LDS accumulators -> global records: consecutive lanes write consecutive qwords of one 128-B record -----------
     constexpr int GQ = CP + 2;   // global record: colours, n | sum_y << 32, sum_x
@@ -544,7 +570,16 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
         else v = (pw >> 40) + n * (unsigned long long)tx0;
         atomicAdd(&acc[(size_t)k * RQ + q], v);
     }
+    STAMP(7)   // barrier + flush
+    STAMP_FLUSH
 }
+
+#ifdef OBIA_STAMP
+extern "C" void obia_debug_stamps(unsigned long long *out16, int reset) {
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+}
+#endif
 
 template <int CP>
 static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color) {
