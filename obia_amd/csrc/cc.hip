@@ -57,36 +57,35 @@ __device__ __forceinline__ void unite(int *parent, int a, int b) {
 __global__ __launch_bounds__(256) void cc_init_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
                                                       int *__restrict__ parent, int *__restrict__ size, int mask_label) {
     const CcProblem P = probs[blockIdx.y];
-    const long long n = (long long)P.H * P.W;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long g = P.pix_off + i;
-        const int l = lab[g];
-        int p = (int)g;
-        // start every pixel at the head of its horizontal run where that is one step away
-        if (l == mask_label) p = -1;
-        else if ((int)(i % P.W) > 0 && lab[g - 1] == l) p = (int)g - 1;
-        parent[g] = p;
-        size[g] = 0;
-    }
+    // blocks walk rows, threads walk the pixels of a row (no integer division per pixel)
+    for (int y = blockIdx.x; y < P.H; y += gridDim.x)
+        for (int x = threadIdx.x; x < P.W; x += blockDim.x) {
+            const long long g = P.pix_off + (long long)y * P.W + x;
+            const int l = lab[g];
+            int p = (int)g;
+            // start every pixel at the head of its horizontal run where that is one step away
+            if (l == mask_label) p = -1;
+            else if (x > 0 && lab[g - 1] == l) p = (int)g - 1;
+            parent[g] = p;
+            size[g] = 0;
+        }
 }
 
 __global__ __launch_bounds__(256) void cc_union_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
                                                        int *__restrict__ parent, int mask_label) {
     const CcProblem P = probs[blockIdx.y];
-    const long long n = (long long)P.H * P.W;
     const int W = P.W;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long g = P.pix_off + i;
-        const int l = lab[g];
-        if (l == mask_label) continue;
-        const int y = (int)(i / W);
-        if (y > 0 && lab[g - W] == l) {
-            // only the first pixel of a horizontal contact needs to issue the union
-            const int x = (int)(i % W);
-            const bool left_same = x > 0 && lab[g - 1] == l && lab[g - W - 1] == l;
-            if (!left_same) unite(parent, (int)g, (int)(g - W));
+    for (int y = 1 + blockIdx.x; y < P.H; y += gridDim.x)
+        for (int x = threadIdx.x; x < W; x += blockDim.x) {
+            const long long g = P.pix_off + (long long)y * W + x;
+            const int l = lab[g];
+            if (l == mask_label) continue;
+            if (lab[g - W] == l) {
+                // only the first pixel of a horizontal contact needs to issue the union
+                const bool left_same = x > 0 && lab[g - 1] == l && lab[g - W - 1] == l;
+                if (!left_same) unite(parent, (int)g, (int)(g - W));
+            }
         }
-    }
 }
 
 // flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
@@ -320,10 +319,9 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
     OBIA_HIP_TRY(hipMemcpyAsync(d_probs, probs.data(), sizeof(CcProblem) * np, hipMemcpyHostToDevice, ctx->stream));
     OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
-    long long maxpix = 1;
-    for (auto &P : probs) { long long m = (long long)P.H * P.W; if (m > maxpix) maxpix = m; }
-    int gx = cdiv(maxpix, 256 * 4);
-    if (gx > 65535 * 4) gx = 65535 * 4;
+    int gx = 1;
+    for (auto &P : probs) if (P.H > gx) gx = P.H;   // row-walking kernels: one block per row (capped)
+    if (gx > 8192) gx = 8192;
     int gs = cdiv(n, 256 * 4);
     if (gs > 65535 * 4) gs = 65535 * 4;
     hipLaunchKernelGGL(cc_init_kernel, dim3(gx, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label);

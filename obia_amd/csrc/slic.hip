@@ -183,9 +183,11 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     }
     const bool vec = (C == CP);                 // C % 4 == 0: aligned float4 reads
     float local_max = 0.0f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(i / wdw.w), x = (int)(i % wdw.w);
+    (void)npix;
+    // blocks walk rows, threads walk the pixels of a row: no integer division per pixel
+    for (int y = blockIdx.x; y < wdw.h; y += gridDim.x)
+    for (int x = threadIdx.x; x < wdw.w; x += blockDim.x) {
+        const long long i = (long long)y * wdw.w + x;
         const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
         float v[CP];
         if (vec) {
@@ -259,9 +261,8 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
                                b.d_windows, d_keys, (int *)d_nonfinite);
     }
     {
-        int blocks = cdiv(maxpix, 256 * 4);
-        if (blocks > 16384) blocks = 16384;
-        dim3 grid(blocks, np);
+        (void)maxpix;
+        dim3 grid(maxh < 4096 ? maxh : 4096, np);
 #define LAUNCH_FEAT(CPV)                                                                                      \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, ctx->stream, src, Ws, C,    \
                        b.d_windows, d_keys, normalize, to_lab, ratio, b.d_feat, d_maxabs)
@@ -300,12 +301,12 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     float maxabs; unsigned mb = host[nkeys + np]; memcpy(&maxabs, &mb, 4);
     if (!(maxabs <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
     // fixed-point scale for the colour sums: totals |feature| * maxcount * 2^s < 2^62, and every partial that is
-    // converted (at most one 64x64 tile of pixels) stays below 2^50 (to_fixed in slic_sweep.hip needs < 2^51)
+    // converted (at most one 128x64 tile of pixels) stays below 2^50 (to_fixed in slic_sweep.hip needs < 2^51)
     long long maxcount = 1;
     for (auto &w : b.windows) { long long n = (long long)w.h * w.w; if (n > maxcount) maxcount = n; }
     double bound = ((double)maxabs + 1e-30) * (double)maxcount;
     int s = 62 - (int)std::ceil(std::log2(bound + 1.0));
-    const int s2 = 50 - (int)std::ceil(std::log2(((double)maxabs + 1e-30) * 4096.0 + 1.0));
+    const int s2 = 50 - (int)std::ceil(std::log2(((double)maxabs + 1e-30) * (double)(SWEEP_TW * SWEEP_TH) + 1.0));
     if (s2 < s) s = s2;
     if (s > 40) s = 40;
     if (s < -60) s = -60;
@@ -527,8 +528,8 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         long long nc = (long long)P.ncy * P.ncx;
         if (cell_off + nc > 0x7fff0000LL) { set_error("too many bins in one batch"); return OBIA_E_INVALID; }
         cell_off += (int)nc;
-        P.tiles_x = cdiv(P.W, SWEEP_TILE);
-        P.tiles_y = cdiv(P.H, SWEEP_TILE);
+        P.tiles_x = cdiv(P.W, SWEEP_TW);
+        P.tiles_y = cdiv(P.H, SWEEP_TH);
         P.tile_off = 0;
         const int nt = P.tiles_x * P.tiles_y;
         if (nt > tile_max) tile_max = nt;

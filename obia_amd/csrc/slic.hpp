@@ -31,7 +31,7 @@ struct SrcWindow {
 // step 0 == slice(None).
 void regular_grid_hw(long long H, long long W, long long n, long long out[4]);
 
-constexpr int SWEEP_TILE = 64;   // pixels per side of the workgroup tile of the sweep kernel
+constexpr int SWEEP_TW = 64, SWEEP_TH = 64;   // workgroup tile of the sweep kernel (pixels)
 constexpr int CENT_REC = 8;      // header dwords of a centroid record: cy, cx, y0, y1, x0, x1, k, -
 // Accumulator record of one centroid, 128-byte aligned so a tile's flush touches two 64-B lines:
 //   q[0..CP)  colour sums, 64-bit fixed point     q[CP] = n | (sum_y << 32)     q[CP+1] = sum_x

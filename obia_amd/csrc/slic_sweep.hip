@@ -10,10 +10,10 @@
 //              truncations), same float32 operation order for d (compiled with -ffp-contract=off), same tie
 //              rule; the sums are exact integers (coordinates) / 64-bit fixed point (colours).
 //
-// Kernel shape (gfx950): one 256-thread workgroup per 64x64 pixel tile.
+// Kernel shape (gfx950): one 256-thread workgroup per 128x64 pixel tile.
 //   1. the workgroup stages into LDS the records of every centroid whose window intersects the tile
 //      (lanes walk the per-bin linked lists built by slic_prep_kernel);
-//   2. each wave walks four 16x16 footprints; a lane owns a 1x4 vertical strip.  Lanes first score the
+//   2. each wave walks eight 16x16 footprints; a lane owns a 1x4 vertical strip.  Lanes first score the
 //      staged candidates in parallel (one candidate per lane): window-intersects-footprint and a lower
 //      bound `lb` of the spatial term over the footprint; candidates are then visited in ascending lb and
 //      the walk stops when lb exceeds the largest current best distance in the wave (d >= spatial >= lb,
@@ -45,7 +45,7 @@ __device__ unsigned long long g_stamp[16];
 constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
 constexpr int PPT = 4;          // pixels per lane (vertical strip)
-constexpr int MAXC = 96;        // LDS candidate slots
+constexpr int MAXC = 128;       // LDS candidate slots (two scoring rounds of 64 lanes)
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
 // write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
@@ -114,25 +114,25 @@ __device__ __forceinline__ unsigned long long to_fixed(double v, double fscale) 
 }
 
 // ---- wave-wide reductions on DPP (no LDS traffic) ---------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-// non-negative floats order like their bit patterns, so min/max run on unsigned integers
+// non-negative floats order like their bit patterns, so min/max run on unsigned integers.  Written as
+// inline asm so that every butterfly step is ONE v_{min,max}_u32 with a DPP operand (hipcc lowers the
+// update_dpp builtin to v_mov + v_mov_dpp + v_min, three VALU issues per step).  A DPP operand written by
+// the previous VALU instruction needs two wait states: the s_nop 1 in front of every step.
+#define OBIA_WAVE_REDUCE(OP)                                                                      \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"      \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_nop 1"                                                                        \
+                 : "+v"(v))
 __device__ __forceinline__ unsigned wave_umax(unsigned v) {
-    v = max(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
-    v = max(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
-    v = max(v, dpp_u32<0x141>(v));   // row_half_mirror
-    v = max(v, dpp_u32<0x140>(v));   // row_mirror
+    OBIA_WAVE_REDUCE("v_max_u32_dpp");   // every lane now holds the maximum of its row of 16
     const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
     const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ unsigned wave_umin(unsigned v) {
-    v = min(v, dpp_u32<0xB1>(v));
-    v = min(v, dpp_u32<0x4E>(v));
-    v = min(v, dpp_u32<0x141>(v));
-    v = min(v, dpp_u32<0x140>(v));
+    OBIA_WAVE_REDUCE("v_min_u32_dpp");
     const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
     const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     return min(min(a, b), min(c, d));
@@ -167,8 +167,8 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                           unsigned long long *__restrict__ acc, int RQ, int accumulate, int start_label, double fscale) {
     constexpr int RS = CENT_REC + CP;
     const float w = P.spatial_w;
-    for (int i = threadIdx.x; i < SWEEP_TILE * SWEEP_TILE; i += NT) {
-        const int y = ty0 + i / SWEEP_TILE, x = tx0 + i % SWEEP_TILE;
+    for (int i = threadIdx.x; i < SWEEP_TW * SWEEP_TH; i += NT) {
+        const int y = ty0 + i / SWEEP_TW, x = tx0 + i % SWEEP_TW;
         if (y >= P.H || x >= P.W) continue;
         const long long pix = P.pix_off + (long long)y * P.W + x;
         if (MASKED && mask[pix] == 0) { labels[pix] = start_label - 1; continue; }
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     if (tile >= P.tiles_x * P.tiles_y) return;
     constexpr int RS = CENT_REC + CP;
     constexpr int AQ = CP + 1;                  // qwords of an LDS accumulator: colours, then one packed word
-                                                //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 64x64 tile: n <= 4096,
-                                                //   sums <= 4096 * 63 < 2^18: no field can carry into the next)
+                                                //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 128x64 tile: n <= 8192,
+                                                //   sums <= 8192 * 127 < 2^20: no field can carry into the next)
     constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
     __shared__ int s_cnt;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ty0 = (tile / P.tiles_x) * SWEEP_TILE, tx0 = (tile % P.tiles_x) * SWEEP_TILE;
-    const int ty1 = min(ty0 + SWEEP_TILE, P.H), tx1 = min(tx0 + SWEEP_TILE, P.W);
+    const int ty0 = (tile / P.tiles_x) * SWEEP_TH, tx0 = (tile % P.tiles_x) * SWEEP_TW;
+    const int ty1 = min(ty0 + SWEEP_TH, P.H), tx1 = min(tx0 + SWEEP_TW, P.W);
 
     STAMP_DECL
     for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
         return;
     }
 
-    // ---- 2. per wave: four 16x16 footprints ----------------------------------------------------------------------
-    for (int bxi = 0; wave_active && bxi < SWEEP_TILE / FB; ++bxi) {
+    // ---- 2. per wave: eight 16x16 footprints (one 16-row band of the 128x64 tile) ----------------------------------------------------------------------
+    for (int bxi = 0; wave_active && bxi < SWEEP_TW / FB; ++bxi) {
         const int fx0 = tx0 + FB * bxi;
         if (fx0 >= P.W) break;   // wave-uniform
         const int fx1 = min(fx0 + FB, P.W);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
             const bool inx = covers || ((x >= x0) && (x < x1));
             float dv[PPT];
             bool cand[PPT];     // this candidate may still win or tie this pixel
-            bool any = false;
+            bool any = false, improved = false;
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
                 const float tyv = cy - fyv[j];
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
                 for (int j = 0; j < PPT; ++j) {
                     const bool lt = cand[j] && (dv[j] < best_d[j]);
                     tie |= cand[j] && (dv[j] == best_d[j]);
+                    improved |= lt;
                     best_d[j] = lt ? dv[j] : best_d[j];
                     best_s[j] = lt ? c : best_s[j];
                 }
@@ -445,9 +446,12 @@ __global__ __launch_bounds__(NT) void slic_assign_kernel(
                     }
                 }
             }
-            // largest best distance in the wave (+inf while a valid pixel is unassigned; invalid pixels hold -inf)
-            const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
-            maxbest = wave_umax(__float_as_uint(lm));
+            // largest best distance in the wave (+inf while a valid pixel is unassigned; invalid pixels hold -inf);
+            // it can only have moved if some lane improved
+            if (__ballot(improved)) {
+                const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
+                maxbest = wave_umax(__float_as_uint(lm));
+            }
         }
         STAMP(3)   // visits
         int best_k[PPT];

@@ -48,17 +48,14 @@ __device__ __forceinline__ bool in_corner(const TileWin &t, int y, int x) {
 __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ G,
                                                                 int Wr, unsigned *__restrict__ inside) {
     const TileWin t = wins[blockIdx.y];
-    const long long n = (long long)t.h * t.w;
-    const long long nround = ((n + 255) / 256) * 256;
-    for (long long i0 = (long long)blockIdx.x * 256; i0 < nround; i0 += (long long)gridDim.x * 256) {
-        const long long i = i0 + threadIdx.x;
-        int g = 0;
-        if (i < n) {
-            const int y = (int)(i / t.w), x = (int)(i % t.w);
-            if (!in_corner(t, y, x)) g = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+    const int wround = ((t.w + 255) / 256) * 256;   // whole waves stay in the loop for the wave-level histogram
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+        for (int x0 = 0; x0 < wround; x0 += 256) {
+            const int x = x0 + threadIdx.x;
+            int g = 0;
+            if (x < t.w && !in_corner(t, y, x)) g = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+            wave_hist_add(inside, g, g > 0);
         }
-        wave_hist_add(inside, g, g > 0);
-    }
 }
 
 // step 2: dense tile mask.  black: the input mask.  white: input mask minus kept (overlapping) segments
@@ -68,9 +65,9 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
                                                         const unsigned *__restrict__ inside, const unsigned *__restrict__ seg_size,
                                                         uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask) {
     const TileWin t = wins[blockIdx.y];
-    const long long n = (long long)t.h * t.w;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(i / t.w), x = (int)(i % t.w);
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+    for (int x = threadIdx.x; x < t.w; x += blockDim.x) {
+        const long long i = (long long)y * t.w + x;
         const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
         uint8_t m = inmask ? (inmask[gp] != 0) : 1;
         if (white) {
@@ -92,21 +89,20 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileWin *__rest
                                                            int32_t *__restrict__ G, int Wr, int id_base,
                                                            unsigned *__restrict__ seg_size) {
     const TileWin t = wins[blockIdx.y];
-    const long long n = (long long)t.h * t.w;
-    const long long nround = ((n + 255) / 256) * 256;
-    for (long long i0 = (long long)blockIdx.x * 256; i0 < nround; i0 += (long long)gridDim.x * 256) {
-        const long long i = i0 + threadIdx.x;
-        int id = 0;
-        if (i < n) {
-            const int l = lab[t.pix_off + i];
-            if (l > 0) {
-                id = id_base + l;
-                const int y = (int)(i / t.w), x = (int)(i % t.w);
-                G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id;
+    const int wround = ((t.w + 255) / 256) * 256;
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+        for (int x0 = 0; x0 < wround; x0 += 256) {
+            const int x = x0 + threadIdx.x;
+            int id = 0;
+            if (x < t.w) {
+                const int l = lab[t.pix_off + (long long)y * t.w + x];
+                if (l > 0) {
+                    id = id_base + l;
+                    G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id;
+                }
             }
+            wave_hist_add(seg_size, id, id > 0);
         }
-        wave_hist_add(seg_size, id, id > 0);
-    }
 }
 
 // final ids 1..N: exclusive scan over the alive flags of the provisional ids (single workgroup)
@@ -150,11 +146,10 @@ struct TileState {
     const obia_slic_params *sp;
 };
 
-static int grid_x(long long maxpix, int per) {
-    int g = cdiv(maxpix, 256LL * per);
-    if (g < 1) g = 1;
-    if (g > 65535) g = 65535;
-    return g;
+static int grid_rows(const std::vector<TileWin> &wins) {   // row-walking kernels: one block per row (capped)
+    int g = 1;
+    for (auto &t : wins) if (t.h > g) g = t.h;
+    return g > 8192 ? 8192 : g;
 }
 
 // One batch of tiles: mask -> features -> plan -> sweeps -> connectivity -> scatter.
@@ -197,9 +192,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (white) {
         OBIA_HIP_TRY(hipMemsetAsync(S.inside, 0, sizeof(unsigned) * (size_t)S.next_id, ctx->stream));
-        hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_x(maxpix, 8), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
+        hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
     }
-    hipLaunchKernelGGL(tile_mask_kernel, dim3(grid_x(maxpix, 8), np), dim3(256), 0, ctx->stream, d_wins, S.inmask, S.G, S.W,
+    hipLaunchKernelGGL(tile_mask_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask, S.G, S.W,
                        white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
     // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
     std::vector<int> skip;
@@ -235,7 +230,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     }
     if (S.next_id + n_new > S.id_cap) { set_error("segment id capacity exceeded (%d + %d > %d)", S.next_id, n_new, S.id_cap); return OBIA_E_NOMEM; }
     if (n_new > 0) {
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_x(maxpix, 8), np), dim3(256), 0, ctx->stream, d_wins, d_final, S.G, S.W,
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, d_final, S.G, S.W,
                            S.next_id - 1, S.seg_size);
         OBIA_HIP_TRY(hipMemsetAsync(S.alive + S.next_id, 1, (size_t)n_new, ctx->stream));
         S.next_id += n_new;
