@@ -127,6 +127,12 @@ typedef struct obia_tiling_params {
     double pixel_height;   /* |geotransform[5]| */
     int32_t tile_size;
     int32_t buffer;
+    int32_t white_order;   /* 0: white tiles in the reference's raster order (tile-row by tile-row);
+                              1: two parity classes of tile rows (even rows, then odd rows) -- the order
+                              the sharded driver needs so that neighbouring slabs never touch the same seam
+                              at once; both orders give the same kind of result, they differ in who wins
+                              the 2*buffer x 2*buffer corner overlaps of diagonal white neighbours          */
+    int32_t reserved;
 } obia_tiling_params;
 
 int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img_hwc, const uint8_t *mask, int H, int W, int C,
@@ -135,6 +141,25 @@ int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img_hwc, const uint8_t *
 int obia_tiled_slic_f32(obia_ctx *ctx, const float *img_hwc, const uint8_t *mask, int H, int W, int C,
                         const obia_tiling_params *tiling, const obia_slic_params *params,
                         int32_t *labels_out, int64_t *n_segments_out);
+
+/* ---- B3, sharded: the same tile loops as a session, for slabs of a raster spread over several GPUs --------
+ * The caller holds rows [row0, row0 + H_local) of a (H_global, W) raster on this GPU: its slab plus the halo
+ * rows its white windows reach (`buffer` rows, +1 label row so that "segment continues beyond the halo" can be
+ * seen).  labels_local (same rows) is the persistent label raster G of the session: provisional ids 1..next_id-1,
+ * 0 = no segment.  Between passes the host exchanges halo rows of G with the neighbouring ranks (RCCL send/recv)
+ * and registers the segments it imported with obia_tiler_set_segments (their pixel counts as seen locally;
+ * 0xffffffff for a segment that continues beyond the halo and can therefore never be "within" a window).
+ * tile rows are GLOBAL indices; row_parity -1 = all rows, 0/1 = rows of that parity (white_order 1).
+ * The context must not be used for other calls while a session is open.                                         */
+typedef struct obia_tiler obia_tiler;
+obia_tiler *obia_tiler_create(obia_ctx *ctx, const float *img_local, const uint8_t *mask_local, int H_local, int W, int C,
+                              int H_global, int row0, const obia_tiling_params *tiling, const obia_slic_params *params,
+                              int32_t *labels_local, int extra_ids);
+void obia_tiler_destroy(obia_tiler *t);
+int obia_tiler_run(obia_tiler *t, int white, int tile_row_lo, int tile_row_hi, int row_parity);
+int obia_tiler_next_id(obia_tiler *t);
+int obia_tiler_set_segments(obia_tiler *t, int first_id, int count, const uint32_t *sizes_dev);
+int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------
  * Time of the most recent call's kernels by class, measured with HIP events on the context's

@@ -27,7 +27,8 @@ class SlicParams(ctypes.Structure):
 class TilingParams(ctypes.Structure):
     """obia_tiling_params (include/obia_hip.h)."""
     _fields_ = [("crown_radius", ctypes.c_double), ("pixel_width", ctypes.c_double),
-                ("pixel_height", ctypes.c_double), ("tile_size", ctypes.c_int32), ("buffer", ctypes.c_int32)]
+                ("pixel_height", ctypes.c_double), ("tile_size", ctypes.c_int32), ("buffer", ctypes.c_int32),
+                ("white_order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p
@@ -51,6 +52,12 @@ _SIGNATURES = {
                                      ctypes.POINTER(ctypes.c_int64)]),
     "obia_tiled_slic_f32": (_I, [_P, _P, _P, _I, _I, _I, ctypes.POINTER(TilingParams), ctypes.POINTER(SlicParams), _P,
                                  ctypes.POINTER(ctypes.c_int64)]),
+    "obia_tiler_create": (_P, [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(TilingParams), ctypes.POINTER(SlicParams), _P, _I]),
+    "obia_tiler_destroy": (None, [_P]),
+    "obia_tiler_run": (_I, [_P, _I, _I, _I, _I]),
+    "obia_tiler_next_id": (_I, [_P]),
+    "obia_tiler_set_segments": (_I, [_P, _I, _I, _P]),
+    "obia_tiler_finalize": (_I, [_P, ctypes.POINTER(ctypes.c_int64)]),
     "obia_set_profiling": (_I, [_P, _I]),
     "obia_last_timing": (ctypes.c_double, [_P, _I]),
 }

@@ -37,7 +37,7 @@ def _open_raster(path):
 
 
 def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method="slic", tile_size=200, buffer=30,
-                          crown_radius=5, pixel_size=None, ctx=None, **kwargs):
+                          crown_radius=5, pixel_size=None, white_order="raster", ctx=None, **kwargs):
     """Tiled SLIC over a large raster.
 
     input_raster : path (GDAL), object with ``img_data``, (H,W,C) NumPy array, or CUDA tensor.
@@ -46,6 +46,8 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
     pixel_size   : (width, height) of a pixel in map units; taken from the geotransform for paths,
         default (1, 1).  Enters the crown rule n = round(valid_px * pixel_area / (pi * crown_radius^2))
         (tiling.py:126-135) and the side of the masked corner squares (buffer/2 map units, tiling.py:189).
+    white_order  : "raster" (the reference's order of white tiles) or "parity" (even tile rows, then odd ones:
+        the order of the multi-GPU driver, obia_amd.distributed).
     kwargs       : SLIC keyword arguments (scikit-image names).  ``n_segments`` (which the reference
         cannot accept: duplicate keyword TypeError, tiling.py:126,137-143) is taken per full tile and
         scaled by the tile's valid area.
@@ -80,8 +82,11 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
                          min_size_factor=kwargs.get("min_size_factor", 0.5),
                          max_size_factor=kwargs.get("max_size_factor", 3), slic_zero=kwargs.get("slic_zero", False),
                          start_label=1, normalize_bands=True)
+    if white_order not in ("raster", "parity"):
+        raise ValueError("white_order must be 'raster' or 'parity'")
     tp = _lib.TilingParams()
     tp.tile_size, tp.buffer = int(tile_size), int(buffer)
+    tp.white_order = 1 if white_order == "parity" else 0
     tp.crown_radius, tp.pixel_width, tp.pixel_height = float(crown_radius), float(pw), float(ph)
     lib = _lib.load()
     n_out = ctypes.c_int64(0)

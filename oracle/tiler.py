@@ -6,6 +6,10 @@ geopandas, none of which exist in the build container: PARITY UNPINNED for this 
 executable reference and no fixture of its output.  This file restates the algorithm from the source
 text, with the polygon predicates replaced by the equivalent pixel counts (tiling.hip header), and the
 per-tile segmentation done by the pinned SLIC oracle with the build's masked-grid seeding rule.
+
+OracleTiler mirrors the session API of the HIP library (obia_tiler_* in include/obia_hip.h): a local block of
+rows [row0, row0+H) of a (Hg, W) raster, passes by global tile-row range and parity, externally registered
+segments.  It is also the compute engine of the CPU (gloo) test of the sharded driver.
 """
 import math
 
@@ -13,75 +17,111 @@ import numpy as np
 
 from . import oracle as orc
 
+HUGE = 0xFFFFFFFF
 
-def create_tiled_segments(img, mask=None, tile_size=200, buffer=30, crown_radius=5, pixel_size=(1.0, 1.0),
-                          n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5):
-    img = np.asarray(img, np.float32)
-    H, W, C = img.shape
-    inmask = np.ones((H, W), bool) if mask is None else (np.asarray(mask) != 0)
-    pw, ph = pixel_size
-    G = np.zeros((H, W), np.int64)
-    sizes = {}
-    alive = {}
-    next_id = 1
-    cl = buffer / 2.0
-    clx = max(0, int(math.ceil(cl / pw - 0.5))) if buffer > 0 else 0
-    cly = max(0, int(math.ceil(cl / ph - 0.5))) if buffer > 0 else 0
 
-    def run_tile(y0, x0, h, w, tmask):
-        nonlocal next_id
-        tile = img[y0:y0 + h, x0:x0 + w].copy()
-        if any(tile[:, :, c].max() == tile[:, :, c].min() for c in range(C)) or not np.isfinite(tile).all():
+class OracleTiler:
+    def __init__(self, img, mask, Hg, row0, tile_size=200, buffer=30, crown_radius=5, pixel_size=(1.0, 1.0),
+                 n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5):
+        self.img = np.asarray(img, np.float32)
+        self.H, self.W, self.C = self.img.shape
+        self.Hg, self.row0 = int(Hg), int(row0)
+        self.inmask = np.ones((self.H, self.W), bool) if mask is None else (np.asarray(mask) != 0)
+        self.T, self.B = int(tile_size), int(buffer)
+        self.crown_radius, (self.pw, self.ph) = crown_radius, pixel_size
+        self.n_segments, self.compactness, self.max_iter, self.msf = n_segments, compactness, max_iter, min_size_factor
+        self.G = np.zeros((self.H, self.W), np.int64)
+        self.sizes = {}
+        self.alive = {}
+        self.next_id = 1
+        cl = self.B / 2.0
+        self.clx = max(0, int(math.ceil(cl / self.pw - 0.5))) if self.B > 0 else 0
+        self.cly = max(0, int(math.ceil(cl / self.ph - 0.5))) if self.B > 0 else 0
+
+    def set_segments(self, first_id, sizes):
+        for i, s in enumerate(sizes):
+            self.sizes[first_id + i] = int(s)
+            self.alive[first_id + i] = True
+        self.next_id = max(self.next_id, first_id + len(sizes))
+
+    def _run_tile(self, y0, x0, h, w, tmask):
+        tile = self.img[y0:y0 + h, x0:x0 + w].copy()
+        if any(tile[:, :, c].max() == tile[:, :, c].min() for c in range(self.C)) or not np.isfinite(tile).all():
             return                                            # NaN features -> ValueError -> "empty tile"
         nvalid = int(tmask.sum())
-        if n_segments is not None:
-            n = round(n_segments * nvalid / float(tile_size * tile_size))
+        if self.n_segments is not None:
+            n = round(self.n_segments * nvalid / float(self.T * self.T))
         else:
-            n = round(nvalid * pw * ph / (math.pi * crown_radius ** 2))      # tiling.py:126-135
+            n = round(nvalid * self.pw * self.ph / (math.pi * self.crown_radius ** 2))      # tiling.py:126-135
         if n < 1 or nvalid == 0:
             return
-        lab = orc.slic(orc.normalize(tile), n_segments=int(n), compactness=compactness, max_iter=max_iter,
-                       mask=tmask.astype(np.uint8), min_size_factor=min_size_factor, max_size_factor=1e9)
-        ids = np.unique(lab[lab > 0])
-        sub = G[y0:y0 + h, x0:x0 + w]
-        for l in ids:                                          # labels are consecutive in first-pixel order
+        lab = orc.slic(orc.normalize(tile), n_segments=int(n), compactness=self.compactness, max_iter=self.max_iter,
+                       mask=tmask.astype(np.uint8), min_size_factor=self.msf, max_size_factor=1e9)
+        sub = self.G[y0:y0 + h, x0:x0 + w]
+        for l in np.unique(lab[lab > 0]):                      # labels are consecutive in first-pixel order
             sel = lab == l
-            sub[sel] = next_id
-            sizes[next_id] = int(sel.sum())
-            alive[next_id] = True
-            next_id += 1
+            sub[sel] = self.next_id
+            self.sizes[self.next_id] = int(sel.sum())
+            self.alive[self.next_id] = True
+            self.next_id += 1
 
-    T = tile_size
-    for j in range(0, H, T):                                   # pass 1: black tiles (tiling.py:103-153)
-        for i in range(0, W, T):
-            if (i // T + j // T) % 2 != 0:
+    def run(self, white, tr_lo, tr_hi, parity=-1):
+        T, B, Hg, W = self.T, self.B, self.Hg, self.W
+        nty = -(-Hg // T)
+        for tj in range(max(0, tr_lo), min(nty, tr_hi)):
+            if parity >= 0 and (tj & 1) != parity:
                 continue
-            h, w = min(T, H - j), min(T, W - i)
-            run_tile(j, i, h, w, inmask[j:j + h, i:i + w])
-    for j in range(0, H, T):                                   # pass 2: white tiles (tiling.py:156-287)
-        for i in range(0, W, T):
-            if (i // T + j // T) % 2 == 0:
-                continue
-            y0, y1 = max(0, j - buffer), min(H, j + T + buffer)
-            x0, x1 = max(0, i - buffer), min(W, i + T + buffer)
-            h, w = y1 - y0, x1 - x0
-            corner = np.zeros((h, w), bool)
-            cy, cx = min(cly, h), min(clx, w)
-            if cy > 0 and cx > 0:
-                corner[h - cy:, :cx] = True
-                corner[h - cy:, w - cx:] = True
-            sub = G[y0:y1, x0:x1]
-            tmask = inmask[y0:y1, x0:x1].copy()
-            inside = sub[~corner]
-            ids, cnt = np.unique(inside[inside > 0], return_counts=True)
-            for g, c in zip(ids, cnt):
-                if c == sizes[g]:                              # within(tile_polygon): dropped (:220-231)
-                    sub[sub == g] = 0
-                    alive[g] = False
-            tmask[sub > 0] = False                             # overlaps: kept and masked out (:213-255)
-            tmask[corner] = False                              # corner squares (:189-203, :248)
-            run_tile(y0, x0, h, w, tmask)
-    order = [g for g in range(1, next_id) if alive.get(g)]
-    lut = np.zeros(next_id + 1, np.int64)
-    lut[order] = np.arange(1, len(order) + 1)                  # segment_id = 1..N (tiling.py:289-290)
-    return lut[G], len(order)
+            for ti in range(-(-W // T)):
+                if ((ti + tj) % 2 != 0) != bool(white):
+                    continue
+                if not white:                                   # pass 1: black tiles (tiling.py:103-153)
+                    gy0, h, x0, w = tj * T, min(T, Hg - tj * T), ti * T, min(T, W - ti * T)
+                    y0 = gy0 - self.row0
+                    assert 0 <= y0 and y0 + h <= self.H
+                    self._run_tile(y0, x0, h, w, self.inmask[y0:y0 + h, x0:x0 + w])
+                    continue
+                gy0, gy1 = max(0, tj * T - B), min(Hg, tj * T + T + B)      # pass 2: white tiles (tiling.py:156-287)
+                x0, x1 = max(0, ti * T - B), min(W, ti * T + T + B)
+                y0, y1 = gy0 - self.row0, gy1 - self.row0
+                assert 0 <= y0 and y1 <= self.H, "halo too small"
+                h, w = y1 - y0, x1 - x0
+                corner = np.zeros((h, w), bool)
+                cy, cx = min(self.cly, h), min(self.clx, w)
+                if cy > 0 and cx > 0:
+                    corner[h - cy:, :cx] = True
+                    corner[h - cy:, w - cx:] = True
+                sub = self.G[y0:y1, x0:x1]
+                tmask = self.inmask[y0:y1, x0:x1].copy()
+                inside = sub[~corner]
+                ids, cnt = np.unique(inside[inside > 0], return_counts=True)
+                for g, c in zip(ids, cnt):
+                    if c == self.sizes[g]:                     # within(tile_polygon): dropped (:220-231)
+                        sub[sub == g] = 0
+                        self.alive[g] = False
+                tmask[sub > 0] = False                         # overlaps: kept and masked out (:213-255)
+                tmask[corner] = False                          # corner squares (:189-203, :248)
+                self._run_tile(y0, x0, h, w, tmask)
+
+    def finalize(self):
+        order = [g for g in range(1, self.next_id) if self.alive.get(g)]
+        lut = np.zeros(self.next_id + 1, np.int64)
+        lut[order] = np.arange(1, len(order) + 1)              # segment_id = 1..N (tiling.py:289-290)
+        return lut[self.G], len(order)
+
+
+def create_tiled_segments(img, mask=None, tile_size=200, buffer=30, crown_radius=5, pixel_size=(1.0, 1.0),
+                          n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5, white_order=0):
+    """white_order 0: the reference's raster order of white tiles; 1: even tile rows, then odd tile rows
+    (the order of the sharded driver)."""
+    img = np.asarray(img, np.float32)
+    H = img.shape[0]
+    t = OracleTiler(img, mask, H, 0, tile_size, buffer, crown_radius, pixel_size, n_segments, compactness, max_iter,
+                    min_size_factor)
+    nty = -(-H // tile_size)
+    t.run(False, 0, nty)
+    if white_order == 1:
+        t.run(True, 0, nty, 0)
+        t.run(True, 0, nty, 1)
+    else:
+        t.run(True, 0, nty)
+    return t.finalize()

@@ -1,0 +1,68 @@
+"""GPU checks of the multi-GPU path on ONE card: (1) the one-GPU tiler in parity order equals the oracle's tiler
+in parity order; (2) two ranks that share cuda:0 (gloo for the seam exchange, the HIP session engine for the
+tile passes) reproduce the one-GPU parity-order partition exactly and own every segment exactly once."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests.metrics import adjusted_rand_index
+from tests.test_distributed_cpu import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_parity_order_vs_oracle(oracle):
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    img = synth(300, 340, 4)
+    kw = dict(tile_size=100, buffer=16, crown_radius=5, pixel_size=(1.0, 1.0), compactness=10.0)
+    ref, n_ref = tiler.create_tiled_segments(img, None, white_order=1, **kw)
+    lab, n = create_tiled_segments(img, white_order="parity", **kw)
+    assert adjusted_rand_index(lab, ref) >= 0.99 and abs(n - n_ref) <= max(1, 0.01 * n_ref)
+    lab_r, n_r = create_tiled_segments(img, white_order="raster", **kw)
+    # the two orders differ only in who wins the corner overlaps of diagonal white neighbours
+    assert adjusted_rand_index(lab, lab_r) >= 0.98 and abs(n - n_r) <= 0.02 * n_r
+
+
+def _worker(rank, world, port, H, W, C, R, kw, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from obia_amd.distributed import ShardedTiler
+        from obia_amd.statistics import zonal_stats
+        img = synth(H, W, C)
+        T = kw["tile_size"]
+        lo, hi = rank * R * T, min(H, (rank + 1) * R * T)
+        slab = torch.from_numpy(img[lo:hi].copy()).cuda()
+        t = ShardedTiler(slab, None, H, R, T, kw["buffer"], kw["crown_radius"], kw["pixel_size"], compactness=kw["compactness"])
+        labels, n = t.run()
+        ext_img, dense, n_owned = t.owned_labels()
+        st = zonal_stats(ext_img, dense, n_labels=n_owned)
+        np.save(os.path.join(out, f"lab{rank}.npy"), labels.cpu().numpy())
+        np.save(os.path.join(out, f"own{rank}.npy"), np.array([n, n_owned, int(st["count"].sum().item())]))
+        t.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    from obia_amd.tiling import create_tiled_segments
+    H, W, C, R = 256, 300, 4, 2
+    kw = dict(tile_size=64, buffer=12, crown_radius=4, pixel_size=(1.0, 1.0), compactness=10.0)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.get_context("spawn")
+    mp.spawn(_worker, args=(2, port, H, W, C, R, kw, str(tmp_path)), nprocs=2, join=True)
+    lab = np.concatenate([np.load(tmp_path / f"lab{r}.npy") for r in range(2)], 0)
+    ref, n_ref = create_tiled_segments(synth(H, W, C), white_order="parity", **kw)
+    own = [np.load(tmp_path / f"own{r}.npy") for r in range(2)]
+    assert own[0][0] == n_ref and own[0][1] + own[1][1] == n_ref          # every segment owned exactly once
+    assert own[0][2] + own[1][2] == int((ref > 0).sum())                   # and every labelled pixel counted once
+    assert np.array_equal(lab == 0, ref == 0)
+    assert adjusted_rand_index(lab, ref) == 1.0
