@@ -89,13 +89,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: obia_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # OBIA_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE card (seam rows staged through
+    # the host); the real runs use RCCL ("nccl") with one rank per GPU.
+    backend = os.environ.get("OBIA_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from obia_amd import _lib
     from obia_amd.statistics import zonal_stats
@@ -115,7 +122,7 @@ def main():
                     f"tile={args.tile}, overlap={args.buffer}, seam exchange over RCCL send/recv")
     img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
     mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(gpu)
     ctx.set_profiling(True)
     kw = dict(tile_size=args.tile, buffer=args.buffer, crown_radius=5, pixel_size=(0.5, 0.5), compactness=args.compactness, ctx=ctx)
 
@@ -158,7 +165,7 @@ def main():
     barrier()
     dt = time.time() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

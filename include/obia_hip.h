@@ -159,6 +159,10 @@ void obia_tiler_destroy(obia_tiler *t);
 int obia_tiler_run(obia_tiler *t, int white, int tile_row_lo, int tile_row_hi, int row_parity);
 int obia_tiler_next_id(obia_tiler *t);
 int obia_tiler_set_segments(obia_tiler *t, int first_id, int count, const uint32_t *sizes_dev);
+/* alive flags of the provisional ids [0, count): 1 = the segment exists, 0 = dropped (it was `within` a white
+ * window) or never created.  A rank that dropped a neighbour's segment tells the owner, which clears the flag. */
+int obia_tiler_get_alive(obia_tiler *t, uint8_t *alive_out_dev, int count);
+int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count);
 int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------

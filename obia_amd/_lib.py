@@ -57,6 +57,8 @@ _SIGNATURES = {
     "obia_tiler_run": (_I, [_P, _I, _I, _I, _I]),
     "obia_tiler_next_id": (_I, [_P]),
     "obia_tiler_set_segments": (_I, [_P, _I, _I, _P]),
+    "obia_tiler_get_alive": (_I, [_P, _P, _I]),
+    "obia_tiler_set_alive": (_I, [_P, _P, _I]),
     "obia_tiler_finalize": (_I, [_P, ctypes.POINTER(ctypes.c_int64)]),
     "obia_set_profiling": (_I, [_P, _I]),
     "obia_last_timing": (ctypes.c_double, [_P, _I]),

@@ -421,6 +421,20 @@ int obia_tiler_set_segments(obia_tiler *t, int first_id, int count, const uint32
     return OBIA_OK;
 }
 
+int obia_tiler_get_alive(obia_tiler *t, uint8_t *alive_out_dev, int count) {
+    if (!t || !alive_out_dev || count < 0 || count > t->S.id_cap) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    OBIA_HIP_TRY(hipMemcpyAsync(alive_out_dev, t->S.alive, (size_t)count, hipMemcpyDeviceToDevice, t->ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
+int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count) {
+    if (!t || !alive_in_dev || count < 0 || count > t->S.id_cap) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    OBIA_HIP_TRY(hipMemcpyAsync(t->S.alive, alive_in_dev, (size_t)count, hipMemcpyDeviceToDevice, t->ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
 int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out) {
     if (!t) { set_error("null tiler"); return OBIA_E_INVALID; }
     return tiler_finalize(t->ctx, t->S, n_segments_out);

@@ -72,6 +72,17 @@ class HipTilerEngine:
         torch.cuda.current_stream(self.G.device).synchronize()
         _lib.check(self.lib.obia_tiler_set_segments(self.h, int(first_id), int(s.numel()), s.data_ptr()))
 
+    def get_alive(self, n):
+        out = torch.zeros((int(n),), dtype=torch.uint8, device=self.G.device)
+        torch.cuda.current_stream(self.G.device).synchronize()
+        _lib.check(self.lib.obia_tiler_get_alive(self.h, out.data_ptr(), int(n)))
+        return out
+
+    def set_alive(self, alive):
+        a = alive.to(device=self.G.device, dtype=torch.uint8).contiguous()
+        torch.cuda.current_stream(self.G.device).synchronize()
+        _lib.check(self.lib.obia_tiler_set_alive(self.h, a.data_ptr(), int(a.numel())))
+
     def close(self):
         if self.h:
             self.lib.obia_tiler_destroy(self.h)
@@ -192,21 +203,21 @@ class ShardedTiler:
         beyond what this rank can see: it can never be `within` one of its windows"""
         if not self.f_ids.numel():
             return
-        G = self.G.to(torch.int64)
+        G = self.G
         span = 2 * self.hb + self.B + 2
         rows = []
         if self.top:
-            rows.append(G[:span])
+            rows.append(G[:span].to(torch.int64))
         if self.bot:
-            rows.append(G[G.shape[0] - span:])
+            rows.append(G[G.shape[0] - span:].to(torch.int64))
         flat = torch.cat([r.reshape(-1) for r in rows])
         nmax = int(self.engine.next_id())
         counts = torch.bincount(flat.clamp(min=0), minlength=nmax)[:nmax]
         outer = []
         if self.top:
-            outer.append(G[0])
+            outer.append(G[0].to(torch.int64))
         if self.bot:
-            outer.append(G[-1])
+            outer.append(G[-1].to(torch.int64))
         edge = torch.unique(torch.cat(outer))
         edge = edge[edge > 0]
         counts[edge] = HUGE
@@ -256,23 +267,53 @@ class ShardedTiler:
         # 2. the pass itself: every tile row of this parity in my slab
         tr_lo = self.rank * self.R
         self.engine.run(True, tr_lo, tr_lo + (-(-Hs // self.T)), cls)
-        # 3. active sides send the halo rows back; the owner overwrites its boundary rows
+        # 3. active sides send the halo rows back (+ one extra row listing the neighbour's segments they dropped:
+        #    [count, code, code, ...]); the owner overwrites its boundary rows and clears those segments
         ops, rbuf = [], {}
+        wdev = "cpu" if self.cpu_comm else self.G.device
         if au:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._codes_of(self.G[:top])), self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[:top], self.rank - 1)), self.rank - 1, self.group))
         if ad:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._codes_of(self.G[top + Hs:])), self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[top + Hs:], self.rank + 1)), self.rank + 1, self.group))
         if pu:
-            rbuf["up"] = torch.empty((hb, self.W), dtype=torch.int64, device="cpu" if self.cpu_comm else self.G.device)
+            rbuf["up"] = torch.empty((hb + 1, self.W), dtype=torch.int64, device=wdev)
             ops.append(dist.P2POp(dist.irecv, rbuf["up"], self.rank - 1, self.group))
         if pd:
-            rbuf["down"] = torch.empty((hb, self.W), dtype=torch.int64, device="cpu" if self.cpu_comm else self.G.device)
+            rbuf["down"] = torch.empty((hb + 1, self.W), dtype=torch.int64, device=wdev)
             ops.append(dist.P2POp(dist.irecv, rbuf["down"], self.rank + 1, self.group))
         _p2p(ops)
         if pu:
-            self.G[top:top + hb] = self._ids_of(rbuf["up"].to(self.G.device)).to(self.G.dtype)
+            buf = rbuf["up"].to(self.G.device)
+            self.G[top:top + hb] = self._ids_of(buf[:hb]).to(self.G.dtype)
+            self._apply_kills(buf[hb])
         if pd:
-            self.G[top + Hs - hb:top + Hs] = self._ids_of(rbuf["down"].to(self.G.device)).to(self.G.dtype)
+            buf = rbuf["down"].to(self.G.device)
+            self.G[top + Hs - hb:top + Hs] = self._ids_of(buf[:hb]).to(self.G.dtype)
+            self._apply_kills(buf[hb])
+
+    def _rows_with_kills(self, rows, owner_rank):
+        """codes of `rows` plus one extra row [count, codes of owner_rank's segments that I dropped in this pass]"""
+        out = torch.zeros((rows.shape[0] + 1, self.W), dtype=torch.int64, device=self.G.device)
+        out[:rows.shape[0]] = self._codes_of(rows)
+        if self.f_ids.numel():
+            alive = self.engine.get_alive(self.engine.next_id()).to(torch.bool)
+            mine = (self.f_codes >> CODE_SHIFT) == (owner_rank + 1)
+            dead = mine & ~alive[self.f_ids]
+            codes = self.f_codes[dead]
+            if codes.numel() >= self.W:
+                raise RuntimeError("kill list longer than a raster row")
+            out[-1, 0] = codes.numel()
+            out[-1, 1:1 + codes.numel()] = codes
+        return out
+
+    def _apply_kills(self, row):
+        n = int(row[0].item())
+        if n == 0:
+            return
+        ids = (row[1:1 + n] & ((1 << CODE_SHIFT) - 1)).to(torch.int64)
+        alive = self.engine.get_alive(self.engine.next_id())
+        alive[ids] = 0
+        self.engine.set_alive(alive)
 
     def run(self):
         """all passes; returns (labels of my slab with global ids 1..N, N)"""
@@ -281,23 +322,59 @@ class ShardedTiler:
         self.engine.run(False, tr_lo, tr_lo + ntr, -1)          # pass 1: black tiles, no communication
         self._white_class(0)
         self._white_class(1)
-        codes = self._codes_of(self.G[self.top:self.top + self.Hs])
-        uniq = torch.unique(codes)
-        uniq = uniq[uniq > 0]
-        # global ids: all_gather of the codes present in every slab (variable length -> pad to the maximum)
-        n_loc = torch.tensor([uniq.numel()], dtype=torch.int64, device="cpu" if self.cpu_comm else uniq.device)
-        sizes = [torch.zeros_like(n_loc) for _ in range(self.world)]
-        dist.all_gather(sizes, n_loc, group=self.group)
-        nmax = int(max(int(s.item()) for s in sizes))
-        pad = torch.full((max(nmax, 1),), -1, dtype=torch.int64, device=n_loc.device)
-        pad[:uniq.numel()] = uniq.to(pad.device)
-        gathered = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(gathered, pad, group=self.group)
-        allc = torch.cat(gathered).to(codes.device)
-        allc = torch.unique(allc[allc > 0])
-        lut_pos = torch.searchsorted(allc, codes.reshape(-1)).clamp(max=max(allc.numel() - 1, 0)).reshape(codes.shape)
-        labels = torch.where(codes > 0, lut_pos + 1, torch.zeros_like(codes)).to(torch.int32)
-        return labels, int(allc.numel())
+        labels, n = self._global_labels()
+        return labels, n
+
+    def _number_segments(self):
+        """ids 1..N over all ranks: rank offsets by all_gather of the alive counts, local order = creation order.
+        Returns (lut over local ids -> global id, newid of my own segments, N)."""
+        nid = int(self.engine.next_id())
+        alive = self.engine.get_alive(nid).to(torch.bool)
+        alive[0] = False
+        own = alive.clone()
+        if self.f_ids.numel():
+            own[self.f_ids] = False
+        newid = torch.cumsum(own.to(torch.int64), 0) * own.to(torch.int64)        # 1-based rank among my alive segments
+        n_alive = int(own.sum().item())
+        cdev = "cpu" if self.cpu_comm else self.G.device
+        mine = torch.tensor([n_alive, nid], dtype=torch.int64, device=cdev)
+        allv = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allv, mine, group=self.group)
+        counts = [int(v[0].item()) for v in allv]
+        nids = [int(v[1].item()) for v in allv]
+        offset = [sum(counts[:r]) for r in range(self.world)]
+        # the neighbours' numbering of THEIR segments that live in my rows: exchange the newid tables (small)
+        tables = {self.rank: newid}
+        ops, rb = [], {}
+        for nb in (self.rank - 1, self.rank + 1):
+            if 0 <= nb < self.world:
+                ops.append(dist.P2POp(dist.isend, self._to_wire(newid), nb, self.group))
+                rb[nb] = torch.empty((nids[nb],), dtype=torch.int64, device=cdev)
+                ops.append(dist.P2POp(dist.irecv, rb[nb], nb, self.group))
+        _p2p(ops)
+        for nb, t in rb.items():
+            tables[nb] = t.to(self.G.device)
+        lut = torch.where(own, newid + offset[self.rank], torch.zeros_like(newid))
+        if self.f_ids.numel():
+            owner = (self.f_codes >> CODE_SHIFT) - 1
+            lid = self.f_codes & ((1 << CODE_SHIFT) - 1)
+            g = torch.zeros_like(lid)
+            for nb, t in tables.items():
+                if nb == self.rank:
+                    continue
+                sel = owner == nb
+                if sel.any():
+                    v = t[lid[sel]]
+                    g[sel] = torch.where(v > 0, v + offset[nb], torch.zeros_like(v))
+            lut[self.f_ids] = torch.where(alive[self.f_ids], g, torch.zeros_like(g))
+        return lut.to(torch.int32), newid.to(torch.int32), sum(counts)
+
+    def _global_labels(self):
+        lut, newid, n = self._number_segments()
+        self._newid = newid
+        Gs = self.G[self.top:self.top + self.Hs]
+        assert int(Gs.max().item()) < lut.numel() and int(Gs.min().item()) >= 0
+        return lut[Gs.to(torch.int64)], n
 
     def owned_labels(self):
         """After run(): (ext_image, ext_labels, n_owned) for per-segment statistics without double counting.
@@ -305,13 +382,25 @@ class ShardedTiler:
         rank OWNS (created by one of its tiles -- all their pixels lie within the halo) and 0 elsewhere, after one
         more exchange of boundary label rows so that the halo reflects the neighbours' final state."""
         top, Hs, hb = self.top, self.Hs, self.hb
-        codes = self._codes_of(self.G)
-        self._exchange_rows(codes, send_top=codes[top:top + hb], send_bot=codes[top + Hs - hb:top + Hs])
-        own = (codes >> CODE_SHIFT) == (self.rank + 1)
-        uniq = torch.unique(codes[own])
-        pos = torch.searchsorted(uniq, codes.reshape(-1)).clamp(max=max(uniq.numel() - 1, 0)).reshape(codes.shape)
-        dense = torch.where(own, pos + 1, torch.zeros_like(codes)).to(torch.int32)
-        return self.engine.img if hasattr(self.engine, "img") else None, dense, int(uniq.numel())
+        # refresh my halo label rows from the neighbours' final boundary rows (codes on the wire)
+        ext_rows = torch.zeros((self.G.shape[0], self.W), dtype=torch.int64, device=self.G.device)
+        send_top = self._codes_of(self.G[top:top + hb])
+        send_bot = self._codes_of(self.G[top + Hs - hb:top + Hs])
+        self._exchange_rows(ext_rows, send_top=send_top, send_bot=send_bot)
+        if self.top:
+            self.G[:top] = self._ids_of(ext_rows[:top]).to(self.G.dtype)
+        if self.bot:
+            self.G[top + Hs:] = self._ids_of(ext_rows[top + Hs:]).to(self.G.dtype)
+        # dense ids of my own alive segments (set by run()); foreign ones -> 0: their owner counts them.  The halo
+        # refresh above may have registered foreign segments that did not exist when run() numbered mine.
+        nid = int(self.engine.next_id())
+        newid = torch.zeros((nid,), dtype=torch.int32, device=self.G.device)
+        newid[:self._newid.numel()] = self._newid
+        if self.f_ids.numel():
+            newid[self.f_ids] = 0
+        assert int(self.G.max().item()) < nid and int(self.G.min().item()) >= 0
+        dense = newid[self.G.to(torch.int64)]
+        return self.engine.img if hasattr(self.engine, "img") else None, dense, int(newid.max().item()) if newid.numel() else 0
 
     def close(self):
         if hasattr(self.engine, "close"):

@@ -38,6 +38,18 @@ class OracleEngine:
     def set_segments(self, first_id, sizes):
         self.t.set_segments(first_id, [int(v) for v in sizes.tolist()])
 
+    def get_alive(self, n):
+        a = torch.zeros((n,), dtype=torch.uint8)
+        for g, v in self.t.alive.items():
+            if g < n and v:
+                a[g] = 1
+        return a
+
+    def set_alive(self, alive):
+        for g in range(1, alive.numel()):
+            if g in self.t.alive:
+                self.t.alive[g] = bool(alive[g])
+
 
 def _worker(rank, world, port, H, W, C, R, kw, mask_on, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
