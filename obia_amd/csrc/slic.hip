@@ -540,7 +540,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const int RS = CENT_REC + b.CP;
     b.d_cent = A.get<float>((size_t)b.total_cent * RS);
-    b.d_head = A.get<int>(b.total_cells);
+    b.d_head = A.get<int>((size_t)b.total_cells * 2);
     b.d_next = A.get<int>(b.total_cent);
     const size_t acc_q = (size_t)b.total_cent * acc_record_qwords(b.CP);
     b.d_acc = A.get<unsigned long long>(acc_q);

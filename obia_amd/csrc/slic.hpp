@@ -56,7 +56,8 @@ struct SlicBatch {
     float *d_seed = nullptr;           // [total_cent][2]
     int *d_cent_prob = nullptr;        // [total_cent]
     float *d_cent = nullptr;           // [total_cent][8 + CP] records
-    int *d_head = nullptr, *d_next = nullptr;
+    int *d_head = nullptr, *d_next = nullptr;   // d_head: two buffers of total_cells (double-buffered per sweep)
+    int *d_head_cur = nullptr;
     unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
     double fscale = 1.0;
 };

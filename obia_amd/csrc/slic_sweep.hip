@@ -55,7 +55,11 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
                                                         int RQ, int first, const float *__restrict__ seed,
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
-                                                        int *__restrict__ next) {
+                                                        int *__restrict__ next, int *__restrict__ head_other,
+                                                        int total_cells) {
+    // the bin heads are double-buffered: while this sweep fills `head`, the buffer of the NEXT sweep is reset here
+    // (saves one memset launch per sweep)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total_cent) return;
     const int p = cent_prob[k];
@@ -593,7 +597,7 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     const int RQ = acc_record_qwords(CP);
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
-                       b.d_feat, b.d_mask, b.d_cent, b.d_head, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
                        accum_color, b.start_label, b.fscale)
     if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
     else LAUNCH_ASSIGN(false, false);
@@ -617,14 +621,19 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
     const int RQ = acc_record_qwords(b.CP);
     bool first = true;
+    int sweep_no = 0;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
     for (int pass = 0; pass < passes; ++pass) {
         const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
         const bool last_pass = (pass == passes - 1);
         for (int it = 0; it < b.max_iter; ++it) {
-            OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));
+            int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
+            int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
+            ++sweep_no;
             hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
                                b.d_cent_prob, b.total_cent, b.CP, RQ, first ? 1 : 0, b.d_seed, b.d_acc, 1.0 / b.fscale,
-                               b.d_cent, b.d_head, b.d_next);
+                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells);
+            b.d_head_cur = head_cur;
             first = false;
             // the update after the very last sweep is never read: skip its accumulation
             const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;

@@ -105,26 +105,43 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileWin *__rest
         }
 }
 
-// final ids 1..N: exclusive scan over the alive flags of the provisional ids (single workgroup)
+// final ids 1..N: exclusive scan over the alive flags of the provisional ids.  Single workgroup (the id table is
+// ~1e6 entries), chunked so that every load is a coalesced 16-byte read.
 __global__ __launch_bounds__(1024) void ids_scan_kernel(const uint8_t *__restrict__ alive, int n_ids, int *__restrict__ newid,
                                                         long long *__restrict__ total) {
-    __shared__ int s_part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n_ids + 1023) / 1024;
-    const int lo = tid * per, hi = min(lo + per, n_ids);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += alive[i] != 0;
-    s_part[tid] = s;
+    __shared__ int s_wave[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_run = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (tid >= off) ? s_part[tid - off] : 0;
+    for (int base = 0; base < n_ids; base += 1024 * 16) {
+        const int i0 = base + tid * 16;
+        unsigned char f[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) f[q] = (i0 + q < n_ids) ? alive[i0 + q] : 0;
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c += f[q] != 0;
+        // inclusive scan of c over the wave (shuffle up), then over the 16 waves
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) s_wave[wv] = inc;
         __syncthreads();
-        s_part[tid] += v;
+        int before = s_run;
+        for (int w2 = 0; w2 < wv; ++w2) before += s_wave[w2];
+        int run = before + inc - c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (i0 + q < n_ids) { if (f[q]) { run += 1; newid[i0 + q] = run; } else newid[i0 + q] = 0; }
+        __syncthreads();
+        if (tid == 1023) s_run = before + inc;
         __syncthreads();
     }
-    int run = s_part[tid] - s;
-    for (int i = lo; i < hi; ++i) { if (alive[i]) { run += 1; newid[i] = run; } else newid[i] = 0; }
-    if (tid == 1023) *total = s_part[1023];
+    if (tid == 0) *total = s_run;
 }
 
 __global__ void ids_apply_kernel(int32_t *__restrict__ G, long long n, const int *__restrict__ newid) {
