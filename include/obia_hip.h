@@ -111,6 +111,19 @@ int obia_zonal_stats_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_t 
                              const int32_t *bands, int n_bands, int n_labels, int start_label,
                              int64_t *count_out, double *mean_out, double *var_out, float *min_out, float *max_out);
 
+/* ---- B1': quickshift (the alternate method of create_segments, segment_boundaries.py:48-49) ------------------
+ * Replaces `segments = quickshift(img_to_segment, **kwargs)`: skimage _quickshift.py:59-74 + _quickshift_cy.pyx.
+ * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64
+ * noise scikit-image adds to the densities, RandomState(random_seed).normal(scale=1e-5) -- generated by the host
+ * (NumPy's legacy stream is stable); NULL = no noise.  labels_out: consecutive ids from 0 in ascending order of the
+ * root pixel (np.unique(...)[1]).  kernel_size <= 5 and 1, 3 or 4 bands in this version.                          */
+int obia_quickshift_f32(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
+                        double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                        int32_t *labels_out, int *n_labels_out);
+int obia_quickshift_f32_dev(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
+                            double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                            int32_t *labels_out, int *n_labels_out);
+
 /* ---- B3: tiled driver ------------------------------------------------------------------------------
  * Replaces the tile loops of create_tiled_segments (tiling.py:103-291) on label rasters: pass 1
  * "black" checkerboard tiles on exact windows, pass 2 "white" tiles on windows grown by `buffer`,

@@ -120,6 +120,62 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
     return out.astype(np.int64)
 
 
+def quickshift(image, ratio=1.0, kernel_size=5, max_dist=10, return_tree=False, sigma=0, convert2lab=True,
+               rng=42, *, random_seed=None, channel_axis=-1, ctx=None, _normalize_bands=False):
+    """Drop-in for ``skimage.segmentation.quickshift`` as obia calls it
+    (obia/segmentation/segment_boundaries.py:48-49), on the GPU, float64 arithmetic.
+
+    The densities get the tie-breaking noise scikit-image adds: ``rng`` (scikit-image >= 0.21:
+    ``np.random.default_rng(rng).normal(scale=1e-5)``) or, when ``random_seed`` is given, the legacy
+    ``np.random.RandomState(random_seed)`` stream of scikit-image < 0.21 (the stream of the golden vectors).
+    NumPy array in -> ``np.int64`` labels out; CUDA tensor in -> int32 CUDA tensor out.
+    """
+    if return_tree:
+        raise NotImplementedError("return_tree=True is not implemented")
+    if np.any(np.asarray(sigma) != 0):
+        raise NotImplementedError("sigma != 0 (Gaussian pre-smoothing) is not implemented; obia never sets it")
+    if channel_axis not in (-1, None, 2):
+        raise NotImplementedError("channel_axis must be -1")
+    if kernel_size < 1:
+        raise ValueError("`kernel_size` should be >= 1.")
+    lib = _lib.load()
+    n_out = ctypes.c_int(0)
+    is_t = _is_torch(image)
+    shape = tuple(image.shape)
+    H, W = shape[0], shape[1]
+    C = 1 if len(shape) == 2 else shape[2]
+    if convert2lab and C != 3:
+        raise ValueError("Only RGB images can be converted to Lab space.")
+    if random_seed is not None:
+        noise = np.random.RandomState(random_seed).normal(scale=0.00001, size=(H, W))
+    else:
+        noise = (rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)).normal(scale=0.00001, size=(H, W))
+    noise = np.ascontiguousarray(noise, np.float64)
+    if is_t:
+        if not image.is_cuda:
+            raise ValueError("torch inputs must live on the GPU; pass a NumPy array for host data")
+        img = (image if image.dim() == 3 else image[..., None]).to(torch.float32).contiguous()
+        dev = img.device.index or 0
+        c = ctx or _lib.default_context(dev)
+        nz = torch.as_tensor(noise, device=img.device)
+        out = torch.empty((H, W), dtype=torch.int32, device=img.device)
+        torch.cuda.current_stream(dev).synchronize()
+        _lib.check(lib.obia_quickshift_f32_dev(c.handle, img.data_ptr(), H, W, C, float(ratio), float(kernel_size),
+                                               float(max_dist), int(bool(convert2lab)), nz.data_ptr(),
+                                               int(bool(_normalize_bands)), out.data_ptr(), ctypes.byref(n_out)))
+        return out
+    img = np.asarray(image)
+    if img.ndim == 2:
+        img = img[..., None]
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    c = ctx or _lib.default_context(0)
+    out = np.empty((H, W), np.int32)
+    _lib.check(lib.obia_quickshift_f32(c.handle, _lib.np_ptr(img), H, W, C, float(ratio), float(kernel_size), float(max_dist),
+                                       int(bool(convert2lab)), _lib.np_ptr(noise), int(bool(_normalize_bands)),
+                                       _lib.np_ptr(out), ctypes.byref(n_out)))
+    return out.astype(np.int64)
+
+
 def enforce_connectivity(labels, min_size, max_size, start_label=1, ctx=None):
     """Connectivity enforcement alone on an int32 CUDA label tensor (stage-level parity hook)."""
     if not _is_torch(labels) or not labels.is_cuda:
@@ -162,18 +218,26 @@ def create_segments(image, segmentation_bands=None, method="slic", inplace_norma
     for band in segmentation_bands:
         if band >= num_bands or band < 0:
             raise IndexError(f"Band index {band} out of range. Available bands indices: 0 to {num_bands - 1}.")
-    if method == "quickshift":
-        raise NotImplementedError("method='quickshift' is not built yet in obia_amd (SURVEY.md 8, row a14)")
-    if method != "slic":
+    if method not in ("slic", "quickshift"):
         raise Exception("An unknown segmentation method was requested.")
-    unknown = [k for k in kwargs if k not in _SLIC_KWARGS]
-    if unknown:
-        raise TypeError(f"slic() got an unexpected keyword argument '{unknown[0]}'")
-    kwargs.setdefault("start_label", 1)   # scikit-image >= 0.19 default (pyproject.toml:23 pins >= 0.23.2)
     if _is_torch(img_data):
         sel = img_data[:, :, list(segmentation_bands)]
     else:
         sel = np.asarray(img_data)[:, :, list(segmentation_bands)]
+    if method == "quickshift":
+        qs_kw = ("ratio", "kernel_size", "max_dist", "return_tree", "sigma", "convert2lab", "rng", "random_seed", "channel_axis")
+        unknown = [k for k in kwargs if k not in qs_kw]
+        if unknown:
+            raise TypeError(f"quickshift() got an unexpected keyword argument '{unknown[0]}'")
+        segments = quickshift(sel, ctx=ctx, _normalize_bands=True, **kwargs)
+        if inplace_normalize and not _is_torch(img_data):
+            for i in range(num_bands):
+                img_data[:, :, i] = normalize_band(img_data[:, :, i])
+        return segments
+    unknown = [k for k in kwargs if k not in _SLIC_KWARGS]
+    if unknown:
+        raise TypeError(f"slic() got an unexpected keyword argument '{unknown[0]}'")
+    kwargs.setdefault("start_label", 1)   # scikit-image >= 0.19 default (pyproject.toml:23 pins >= 0.23.2)
     # normalisation is per band, so selecting first and normalising the selected bands is identical
     segments = slic(sel, ctx=ctx, _normalize_bands=True, **kwargs)
     if inplace_normalize and not _is_torch(img_data):

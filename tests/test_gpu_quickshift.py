@@ -1,0 +1,53 @@
+"""GPU parity of quickshift (BASELINE config 5) against the scikit-image 0.18.3 golden vectors and
+the oracle.  float64 on both sides; the only difference is exp/pow/cbrt (device libm vs glibc), which can flip a
+parent only on near-ties: stated tolerance ARI >= 0.99, label count within 2 %."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.metrics import adjusted_rand_index
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_quickshift_vs_skimage_goldens():
+    from obia_amd.segmentation import quickshift
+    z = np.load(os.path.join(GOLD, "quickshift_small.npz"))
+    for i in range(3):
+        ks, md = z[f"par{i}"]
+        raw = z[f"raw{i}"].astype(np.float32)
+        lab = quickshift(raw, ratio=1.0, kernel_size=float(ks), max_dist=float(md), convert2lab=True, random_seed=42,
+                         _normalize_bands=True)
+        gold = z[f"labels{i}"]
+        assert lab.shape == gold.shape and lab.dtype == np.int64
+        ari = adjusted_rand_index(lab, gold)
+        n_l, n_g = len(np.unique(lab)), len(np.unique(gold))
+        assert ari >= 0.99, f"case {i}: ARI {ari} ({(lab != gold).mean():.3%} px differ)"
+        assert abs(n_l - n_g) <= max(1, 0.02 * n_g)
+        assert lab.min() == 0 and lab.max() == n_l - 1          # consecutive ids by root order
+
+
+def test_quickshift_vs_oracle_nolab_and_device_entry(oracle):
+    from obia_amd.segmentation import quickshift, create_segments
+    rs = np.random.RandomState(3)
+    H, W = 70, 90
+    img = np.zeros((H, W, 3), np.float32)
+    img[:35, :45, 0] = 1; img[35:, :45, 1] = 1; img[35:, 45:, 2] = 1
+    img = np.clip(img + 0.05 * rs.normal(size=img.shape), 0, 1).astype(np.float32)
+    noise = np.random.RandomState(7).normal(scale=0.00001, size=(H, W))
+    ref = oracle.quickshift_core(img.astype(np.float64) * 0.8, noise, 3.0, 8.0)
+    lab = quickshift(img, ratio=0.8, kernel_size=3, max_dist=8, convert2lab=False, random_seed=7)
+    assert adjusted_rand_index(lab, ref) >= 0.99
+    lab_t = quickshift(torch.as_tensor(img).cuda(), ratio=0.8, kernel_size=3, max_dist=8, convert2lab=False, random_seed=7)
+    assert np.array_equal(lab_t.cpu().numpy(), lab)
+    # create_segments(method="quickshift") normalises every band first, like the reference
+    seg = create_segments(img * 1000.0 + 5.0, method="quickshift", ratio=0.8, kernel_size=3, max_dist=8, convert2lab=False,
+                          random_seed=7)
+    assert seg.shape == (H, W)
+    with pytest.raises(ValueError):
+        quickshift(np.zeros((8, 8, 4), np.float32), convert2lab=True)
+    with pytest.raises(NotImplementedError):
+        quickshift(img, kernel_size=9)
