@@ -45,7 +45,7 @@ __device__ unsigned long long g_stamp[16];
 constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
 constexpr int PPT = 4;          // pixels per lane (vertical strip)
-constexpr int MAXC = 128;       // LDS candidate slots (two scoring rounds of 64 lanes)
+constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); 96 keeps 5 workgroups per CU
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
 // write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
@@ -220,7 +220,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 
 // K2: the sweep.  grid = (max tiles per problem, nprob).
 template <int CP, bool MASKED, bool IGNORE_COLOR>
-__global__ __launch_bounds__(NT) void slic_assign_kernel(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
     int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,
