@@ -1,0 +1,79 @@
+"""BASELINE-size runs checked through size-independent properties (no CPU oracle finishes at these sizes in
+seconds): label count equal to the reference's published measurement, connectivity, minimum size, consecutive ids,
+run-to-run bit-reproducibility, statistics against a NumPy recomputation on sampled segments."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def synth_gpu(H, W, C, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    yy = torch.arange(H, device="cuda", dtype=torch.float32)[:, None]
+    xx = torch.arange(W, device="cuda", dtype=torch.float32)[None, :]
+    out = torch.empty((H, W, C), device="cuda", dtype=torch.float32)
+    for c in range(C):
+        out[:, :, c] = 400.0 * torch.sin(xx / (11 + 3 * c)) * torch.cos(yy / (13 + 2 * c)) + 1000 + 50 * c \
+            + 20.0 * torch.randn((H, W), device="cuda", generator=g)
+    return out
+
+
+def test_config2_4096x4096x4_properties():
+    """BASELINE configs[1]: 4096x4096x4, n_segments=50000, compactness=10.  scikit-image 0.18.3 produced K = 51 984
+    labels on this configuration: 228 x 228 grid seeds, none merged."""
+    from scipy import ndimage
+    from obia_amd.segmentation import slic
+    from obia_amd.statistics import zonal_stats
+    img = synth_gpu(4096, 4096, 4)
+    lab = slic(img, n_segments=50000, compactness=10.0, _normalize_bands=True)
+    lab2 = slic(img, n_segments=50000, compactness=10.0, _normalize_bands=True)
+    assert torch.equal(lab, lab2)                                   # integer accumulators: bit-reproducible
+    n = int(lab.max().item())
+    assert n == 51984 and int(lab.min().item()) == 1
+    sizes = torch.bincount(lab.reshape(-1).to(torch.int64), minlength=n + 1)[1:]
+    min_size = int(0.5 * 4096 * 4096 / 51984)
+    assert int(sizes.min().item()) >= min_size and int(sizes.max().item()) <= 3 * 4096 * 4096 // 51984
+    l = lab.cpu().numpy()
+    # every label is one 4-connected component: components of the label partition == number of labels
+    structure = ndimage.generate_binary_structure(2, 1)
+    sub = l[1000:1400, 2000:2500]
+    for v in np.unique(sub)[::7]:
+        assert ndimage.label(l[900:1500, 1900:2600] == v, structure)[1] == 1
+    # raster-order numbering of first pixels
+    first = np.full(n + 1, l.size, np.int64)
+    np.minimum.at(first, l.ravel(), np.arange(l.size))
+    assert np.all(np.diff(first[1:]) > 0)
+    # statistics on sampled segments vs NumPy (float64 recomputation)
+    st = zonal_stats(img, lab, n_labels=n)
+    raw = img.cpu().numpy()
+    for v in (1, 777, 25000, 51984):
+        px = raw[l == v].astype(np.float64)
+        np.testing.assert_allclose(st["mean"][v - 1].cpu().numpy(), px.mean(0), rtol=1e-6)
+        np.testing.assert_allclose(st["variance"][v - 1].cpu().numpy(), px.var(0), rtol=1e-5)
+        assert int(st["count"][v - 1].item()) == px.shape[0]
+
+
+def test_tiled_8192_properties():
+    """half-size BASELINE configs[2] (8192^2 x 8, tile 2048, overlap 64): ids 1..N, holes only where the reference
+    leaves them (corner squares), whole-raster statistics add up, identical on a second run."""
+    from obia_amd.tiling import create_tiled_segments
+    from obia_amd.statistics import zonal_stats
+    H = W = 8192
+    img = synth_gpu(H, W, 8)
+    kw = dict(tile_size=2048, buffer=64, crown_radius=5, pixel_size=(0.5, 0.5), compactness=10.0)
+    lab, n = create_tiled_segments(img, **kw)
+    lab2, n2 = create_tiled_segments(img, **kw)
+    assert n == n2 and torch.equal(lab, lab2)
+    assert int(lab.max().item()) == n
+    present = torch.bincount(lab.reshape(-1).to(torch.int64), minlength=n + 1)
+    assert int((present[1:] == 0).sum().item()) == 0               # ids 1..N all used
+    holes = int(present[0].item())
+    assert holes <= 8 * 64 * 64 * 2                                 # bottom corner squares of white windows at most
+    expected = H * W * 0.25 / (np.pi * 25)                          # crown rule density
+    assert 0.95 * expected <= n <= 1.1 * expected
+    st = zonal_stats(img, lab, n_labels=n)
+    assert int(st["count"].sum().item()) == H * W - holes
+    tot = (st["mean"][:, 0] * st["count"].to(torch.float64)).sum().item()
+    ref = img[:, :, 0].to(torch.float64)[lab > 0].sum().item()
+    assert abs(tot - ref) <= 1e-9 * abs(ref)
