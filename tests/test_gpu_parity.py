@@ -110,6 +110,25 @@ def test_slic_matches_oracle_bit_exact_when_centroids_agree(amd, oracle):
     assert np.array_equal(pre, o_pre)
 
 
+@pytest.mark.parametrize("shape,n_seg,comp", [((96, 96, 4), 576, 10.0), ((130, 70, 8), 1200, 0.5), ((64, 200, 3), 3000, 1.0)])
+def test_dense_seeds_take_the_direct_bin_path(amd, oracle, shape, n_seg, comp):
+    """S = 2..4 pixels: a 64x64 tile meets hundreds of candidate centroids, more than the LDS slots of the sweep
+    kernel, so the tile takes slow_tile() (bins read directly from global memory).  Same arithmetic: the labels must
+    still equal the oracle's."""
+    from obia_amd.segmentation import slic
+    rs = np.random.RandomState(11)
+    H, W, C = shape
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    raw = np.stack([400 * np.sin(xx / (5 + c)) * np.cos(yy / (7 + c)) + 1000 + rs.normal(0, 30, (H, W)) for c in range(C)],
+                   -1).astype(np.float32)
+    kw = dict(n_segments=n_seg, compactness=comp, convert2lab=False)
+    lab = slic(raw, _normalize_bands=True, **kw)
+    ref, pre, _ = oracle.slic(oracle.normalize(raw), return_all=True, **kw)
+    got_pre = slic(dev(raw), _normalize_bands=True, _stage="pre", **kw).cpu().numpy()
+    assert label_disagreement(got_pre, pre) <= 1e-4
+    assert adjusted_rand_index(lab, ref) >= 0.99
+
+
 @pytest.mark.parametrize("name", [c for c in SLIC_CASES if c.startswith("mask")])
 def test_masked_slic_vs_oracle_same_rule(amd, oracle, name):
     """maskSLIC: the HIP path and the oracle use the same deterministic masked-grid seeding,
