@@ -54,38 +54,111 @@ __device__ __forceinline__ void unite(int *parent, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void cc_init_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
-                                                      int *__restrict__ parent, int *__restrict__ size, int mask_label) {
-    const CcProblem P = probs[blockIdx.y];
-    // blocks walk rows, threads walk the pixels of a row (no integer division per pixel)
-    for (int y = blockIdx.x; y < P.H; y += gridDim.x)
-        for (int x = threadIdx.x; x < P.W; x += blockDim.x) {
-            const long long g = P.pix_off + (long long)y * P.W + x;
-            const int l = lab[g];
-            int p = (int)g;
-            // start every pixel at the head of its horizontal run where that is one step away
-            if (l == mask_label) p = -1;
-            else if (x > 0 && lab[g - 1] == l) p = (int)g - 1;
-            parent[g] = p;
-            size[g] = 0;
-        }
+// ---- tile-local union-find in LDS -------------------------------------------------------------------------------
+// A workgroup resolves the components of one 64x32 pixel tile entirely in LDS (labels + 16-bit local parents),
+// then publishes parent[pixel] = GLOBAL index of the pixel's tile-local root.  Local indices are row-major inside
+// the tile, so "smaller local index" == "smaller global index": the local root is the first pixel of the tile's
+// part of the component, and linking larger roots under smaller ones across tiles (cc_seam_kernel) keeps the
+// global invariant root == first pixel in raster order.
+constexpr int CT_W = 64, CT_H = 32, CT_N = CT_W * CT_H;
+
+__device__ __forceinline__ int lfind(const unsigned short *par, int i) {
+    int p;
+    while ((p = par[i]) != i) i = p;
+    return i;
+}
+// 16-bit atomicMin on LDS (CAS on the enclosing 32-bit word); returns the previous value of par[i]
+__device__ __forceinline__ int latomic_min16(unsigned short *par, int i, int v) {
+    unsigned *wptr = reinterpret_cast<unsigned *>(par) + (i >> 1);
+    const int sh = (i & 1) * 16;
+    unsigned seen = *wptr;
+    for (;;) {
+        const int cur = (int)((seen >> sh) & 0xffffu);
+        if (cur <= v) return cur;
+        const unsigned prev = atomicCAS(wptr, seen, (seen & ~(0xffffu << sh)) | ((unsigned)v << sh));
+        if (prev == seen) return cur;
+        seen = prev;
+    }
+}
+__device__ __forceinline__ void lunite(unsigned short *par, int a, int b) {
+    for (;;) {
+        a = lfind(par, a);
+        b = lfind(par, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        const int old = latomic_min16(par, b, a);
+        if (old == b) return;   // b was a root and now hangs under a
+        b = old;                // b had been linked elsewhere meanwhile: unite a with where it points
+    }
 }
 
-__global__ __launch_bounds__(256) void cc_union_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
-                                                       int *__restrict__ parent, int mask_label) {
+__global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
+                                                      int *__restrict__ parent, int *__restrict__ size, int mask_label) {
+    __shared__ int s_lab[CT_N];
+    __shared__ unsigned short s_par[CT_N];
+    const CcProblem P = probs[blockIdx.y];
+    const int tiles_x = (P.W + CT_W - 1) / CT_W;
+    const int tile = blockIdx.x;
+    if (tile >= tiles_x * ((P.H + CT_H - 1) / CT_H)) return;
+    const int ty0 = (tile / tiles_x) * CT_H, tx0 = (tile % tiles_x) * CT_W;
+    const int tid = threadIdx.x;
+    // 1. labels -> LDS; parents start at the head of the horizontal run where that is one step away
+    for (int i = tid; i < CT_N; i += 256) {
+        const int ly = i / CT_W, lx = i % CT_W;
+        const int y = ty0 + ly, x = tx0 + lx;
+        s_lab[i] = (y < P.H && x < P.W) ? lab[P.pix_off + (long long)y * P.W + x] : mask_label;
+    }
+    __syncthreads();
+    for (int i = tid; i < CT_N; i += 256) {
+        const int lx = i % CT_W;
+        const int l = s_lab[i];
+        s_par[i] = (unsigned short)((l != mask_label && lx > 0 && s_lab[i - 1] == l) ? i - 1 : i);
+    }
+    __syncthreads();
+    // 2. vertical contacts (only the first pixel of a horizontal contact issues the union)
+    for (int i = tid + CT_W; i < CT_N; i += 256) {
+        const int lx = i % CT_W;
+        const int l = s_lab[i];
+        if (l == mask_label || s_lab[i - CT_W] != l) continue;
+        const bool left_same = lx > 0 && s_lab[i - 1] == l && s_lab[i - CT_W - 1] == l;
+        if (!left_same) lunite(s_par, i, i - CT_W);
+    }
+    __syncthreads();
+    // 3. publish: global index of the local root
+    for (int i = tid; i < CT_N; i += 256) {
+        const int ly = i / CT_W, lx = i % CT_W;
+        const int y = ty0 + ly, x = tx0 + lx;
+        if (y >= P.H || x >= P.W) continue;
+        const long long g = P.pix_off + (long long)y * P.W + x;
+        int p = -1;
+        if (s_lab[i] != mask_label) {
+            const int r = lfind(s_par, i);
+            p = (int)(P.pix_off + (long long)(ty0 + r / CT_W) * P.W + tx0 + r % CT_W);
+        }
+        parent[g] = p;
+        size[g] = 0;
+    }
+}
+
+// contacts across tile borders: the pixels of the first row / first column of every tile against their upper / left
+// neighbour (a few percent of the pixels), on the global parents
+__global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
+                                                      int *__restrict__ parent, int mask_label) {
     const CcProblem P = probs[blockIdx.y];
     const int W = P.W;
-    for (int y = 1 + blockIdx.x; y < P.H; y += gridDim.x)
-        for (int x = threadIdx.x; x < W; x += blockDim.x) {
-            const long long g = P.pix_off + (long long)y * W + x;
-            const int l = lab[g];
-            if (l == mask_label) continue;
-            if (lab[g - W] == l) {
-                // only the first pixel of a horizontal contact needs to issue the union
-                const bool left_same = x > 0 && lab[g - 1] == l && lab[g - W - 1] == l;
-                if (!left_same) unite(parent, (int)g, (int)(g - W));
-            }
-        }
+    const int n_hrows = (P.H - 1) / CT_H;          // horizontal seams: rows CT_H, 2*CT_H, ...
+    const int n_vcols = (W - 1) / CT_W;            // vertical seams: columns CT_W, 2*CT_W, ...
+    const long long n_h = (long long)n_hrows * W, n_v = (long long)n_vcols * P.H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_h + n_v; i += (long long)gridDim.x * blockDim.x) {
+        int y, x, dy, dx;
+        if (i < n_h) { y = (int)(i / W + 1) * CT_H; x = (int)(i % W); dy = 1; dx = 0; }
+        else { const long long j = i - n_h; x = (int)(j / P.H + 1) * CT_W; y = (int)(j % P.H); dy = 0; dx = 1; }
+        const long long g = P.pix_off + (long long)y * W + x;
+        const int l = lab[g];
+        if (l == mask_label) continue;
+        const long long gn = g - (long long)dy * W - dx;
+        if (lab[gn] == l) unite(parent, (int)g, (int)gn);
+    }
 }
 
 // flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
@@ -319,13 +392,22 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
     OBIA_HIP_TRY(hipMemcpyAsync(d_probs, probs.data(), sizeof(CcProblem) * np, hipMemcpyHostToDevice, ctx->stream));
     OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
-    int gx = 1;
-    for (auto &P : probs) if (P.H > gx) gx = P.H;   // row-walking kernels: one block per row (capped)
-    if (gx > 8192) gx = 8192;
     int gs = cdiv(n, 256 * 4);
     if (gs > 65535 * 4) gs = 65535 * 4;
-    hipLaunchKernelGGL(cc_init_kernel, dim3(gx, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label);
-    hipLaunchKernelGGL(cc_union_kernel, dim3(gx, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
+    {
+        int max_tiles = 1;
+        long long max_seam = 1;
+        for (auto &P : probs) {
+            const int t = cdiv(P.W, CT_W) * cdiv(P.H, CT_H);
+            if (t > max_tiles) max_tiles = t;
+            const long long sm = (long long)((P.H - 1) / CT_H) * P.W + (long long)((P.W - 1) / CT_W) * P.H;
+            if (sm > max_seam) max_seam = sm;
+        }
+        hipLaunchKernelGGL(cc_tile_kernel, dim3(max_tiles, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label);
+        int sg = cdiv(max_seam, 256);
+        if (sg > 65535) sg = 65535;
+        hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
+    }
     hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n);
     hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters);
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
