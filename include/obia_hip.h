@@ -67,6 +67,12 @@ typedef struct obia_slic_params {
     int32_t start_label;           /* 0 or 1                                                          */
     int32_t normalize_bands;       /* 1: apply normalize_band (segment_boundaries.py:11-16,32-33) to
                                       every band before segmenting, as create_segments does           */
+    int32_t exit_on_fixed_point;   /* 1: stop sweeping a raster / tile as soon as a sweep starts from centroid
+                                      records that are bit-identical to those of the previous sweep: every
+                                      later sweep would reproduce the same labels and the same centroids, so
+                                      the result is bit-identical to running all max_num_iter sweeps (the
+                                      reference's own `if change == 0: break` intends this but never fires).
+                                      0: always run max_num_iter sweeps.  Default 0.                    */
 } obia_slic_params;
 
 void obia_slic_default_params(obia_slic_params *p);
@@ -182,7 +188,8 @@ int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
  * Time of the most recent call's kernels by class, measured with HIP events on the context's
  * stream (bench.py's roofline leg).  `what`: 0 = SLIC colour sweeps (sum of launches, ms), 1 = number of
  * those launches, 2 = feature preparation, 3 = connectivity, 4 = zonal statistics, 5 = whole call,
- * 6 = maskSLIC spatial-only pre-pass sweeps (ms), 7 = pixels covered by the launches of 0 (sum).      */
+ * 6 = maskSLIC spatial-only pre-pass sweeps (ms), 7 = pixels actually processed by the launches of 0
+ * (sum; tiles skipped by exit_on_fixed_point are not counted), 8 = the same for the pre-pass launches.    */
 int obia_set_profiling(obia_ctx *ctx, int enabled);
 double obia_last_timing(obia_ctx *ctx, int what);
 

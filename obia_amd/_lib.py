@@ -21,7 +21,8 @@ class SlicParams(ctypes.Structure):
                 ("max_size_factor", ctypes.c_double), ("n_segments", ctypes.c_int32),
                 ("max_num_iter", ctypes.c_int32), ("convert2lab", ctypes.c_int32),
                 ("enforce_connectivity", ctypes.c_int32), ("slic_zero", ctypes.c_int32),
-                ("start_label", ctypes.c_int32), ("normalize_bands", ctypes.c_int32)]
+                ("start_label", ctypes.c_int32), ("normalize_bands", ctypes.c_int32),
+                ("exit_on_fixed_point", ctypes.c_int32)]
 
 
 class TilingParams(ctypes.Structure):
@@ -146,7 +147,8 @@ class Context:
 
     def timing(self):
         lib = load()
-        names = ["assign_ms", "sweeps", "features_ms", "connectivity_ms", "zonal_ms", "total_ms", "prepass_ms", "assign_px"]
+        names = ["assign_ms", "sweeps", "features_ms", "connectivity_ms", "zonal_ms", "total_ms", "prepass_ms", "assign_px",
+                 "prepass_px"]
         return {n: lib.obia_last_timing(self._h, i) for i, n in enumerate(names)}
 
     def workspace_bytes(self):

@@ -38,6 +38,7 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.masked = mask != nullptr;
     b.start_label = p->start_label;
     b.max_iter = p->max_num_iter;
+    b.exit_on_fixed_point = p->exit_on_fixed_point != 0;
     b.total_pix = (long long)H * W;
     SlicProblem P{};
     P.H = H; P.W = W; P.pix_off = 0;

@@ -225,6 +225,7 @@ void obia_slic_default_params(obia_slic_params *p) {
     p->slic_zero = 0;
     p->start_label = 1;
     p->normalize_bands = 0;
+    p->exit_on_fixed_point = 0;
 }
 
 int obia_set_profiling(obia_ctx *ctx, int enabled) {
@@ -244,6 +245,7 @@ double obia_last_timing(obia_ctx *ctx, int what) {
         case 5: return ctx->timing.total_ms;
         case 6: return ctx->timing.prepass_ms;
         case 7: return ctx->timing.assign_px;
+        case 8: return ctx->timing.prepass_px;
         default: return -1.0;
     }
 }

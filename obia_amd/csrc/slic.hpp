@@ -60,6 +60,8 @@ struct SlicBatch {
     int *d_head_cur = nullptr;
     unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
     double fscale = 1.0;
+    bool exit_on_fixed_point = false;
+    int *d_state = nullptr;            // [nprob] frozen flags, then [2*max_iter][nprob] per-sweep `changed` flags, then pixel counter
 };
 
 // Feature preparation for every problem of the batch: per-band min/max of its window, then

@@ -56,7 +56,12 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
                                                         int *__restrict__ next, int *__restrict__ head_other,
-                                                        int total_cells) {
+                                                        int total_cells, const int *__restrict__ frozen,
+                                                        int *__restrict__ changed, int force) {
+    // Fixed-point detection (exit_on_fixed_point): `changed[p]` is raised when any centroid record of problem p
+    // differs from the record of the previous sweep; a problem none of whose records moved is frozen by the sweep
+    // kernel and skipped from then on.  `force` re-runs a frozen problem from its standing records (last pre-pass
+    // sweep: its colour means seed the main pass).
     // the bin heads are double-buffered: while this sweep fills `head`, the buffer of the NEXT sweep is reset here
     // (saves one memset launch per sweep)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
@@ -68,11 +73,20 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     if (k - P.cent_off >= P.K) return;
     const int RS = CENT_REC + CP;
     float *rec = cent + (size_t)k * RS;
+    const bool is_frozen = frozen && frozen[p];
+    if (is_frozen && !force) return;
     float cy, cx;
-    if (first) {
+    bool moved = false;
+    if (is_frozen) {            // forced sweep of a frozen problem: keep the standing record, only re-bin it
+        cy = rec[0]; cx = rec[1];
+        unsigned long long *a = acc + (size_t)k * RQ;
+        for (int c = 0; c < CP + 2; ++c) a[c] = 0;
+        moved = true;
+    } else if (first) {
         cy = seed[2 * (size_t)k];
         cx = seed[2 * (size_t)k + 1];
         for (int c = 0; c < CP; ++c) rec[CENT_REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
+        moved = true;
     } else {
         unsigned long long *a = acc + (size_t)k * RQ;
         const unsigned long long ny = a[CP];
@@ -83,11 +97,17 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
         cx = (float)(unsigned)a[CP + 1] / fn;
         for (int c = 0; c < CP; ++c) {
             const float s = (float)((double)(long long)a[c] * inv_fscale);
-            rec[CENT_REC + c] = s / fn;
+            const float v = s / fn;
+            moved |= __float_as_uint(v) != __float_as_uint(rec[CENT_REC + c]);
+            rec[CENT_REC + c] = v;
             a[c] = 0;
         }
         a[CP] = 0; a[CP + 1] = 0;
+        moved |= __float_as_uint(cy) != __float_as_uint(rec[0]) || __float_as_uint(cx) != __float_as_uint(rec[1]);
     }
+    // lanes of one wave can belong to different problems; test before the atomic so that a problem whose flag is
+    // already up costs a cached read, not an atomic per centroid
+    if (changed && moved && __hip_atomic_load(&changed[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&changed[p], 1);
     rec[0] = cy; rec[1] = cx;
     int *irec = reinterpret_cast<int *>(rec);
     irec[6] = k; irec[7] = 0;
@@ -224,13 +244,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
     int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,
-    int start_label, double fscale) {
+    int start_label, double fscale, int *__restrict__ frozen, const int *__restrict__ changed, int force,
+    unsigned long long *__restrict__ px_counter) {
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
     // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
     const SlicProblem P = probs[blockIdx.y];
     const int tile = blockIdx.x;
     if (tile >= P.tiles_x * P.tiles_y) return;
+    if (frozen && !force) {
+        // exit_on_fixed_point: this sweep starts from records bit-identical to the previous sweep's (no centroid of
+        // the problem moved): it would reproduce the same labels and the same sums.  Freeze the problem.
+        if (frozen[blockIdx.y]) return;
+        if (!changed[blockIdx.y]) { if (threadIdx.x == 0) frozen[blockIdx.y] = 1; return; }
+    }
+    if (px_counter && tile == 0 && threadIdx.x == 0) atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
     constexpr int RS = CENT_REC + CP;
     constexpr int AQ = CP + 1;                  // qwords of an LDS accumulator: colours, then one packed word
                                                 //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 128x64 tile: n <= 8192,
@@ -590,7 +618,8 @@ extern "C" void obia_debug_stamps(unsigned long long *out16, int reset) {
 #endif
 
 template <int CP>
-static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color) {
+static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color, int *frozen,
+                          const int *changed, int force, unsigned long long *px_counter) {
     dim3 grid(b.total_tiles, b.nprob);
     static const int ablate = getenv("OBIA_ABLATE") ? atoi(getenv("OBIA_ABLATE")) : 0;   // timing experiments only
     if (ablate & 1) accumulate = 0;
@@ -598,7 +627,7 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
-                       accum_color, b.start_label, b.fscale)
+                       accum_color, b.start_label, b.fscale, frozen, changed, force, px_counter)
     if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
     else LAUNCH_ASSIGN(false, false);
 #undef LAUNCH_ASSIGN
@@ -620,19 +649,32 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
     const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
     const int RQ = acc_record_qwords(b.CP);
+    const int np = b.nprob;
+    // state: frozen[np] | changed[passes*max_iter][np] | 2 pixel counters (colour sweeps, pre-pass sweeps) as u64
+    const size_t n_state = (size_t)np * (1 + (size_t)passes * b.max_iter) + 4;
+    b.d_state = ctx->arena.get<int>(n_state);
+    if (!b.d_state) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_state, 0, sizeof(int) * n_state, ctx->stream));
+    int *d_frozen = b.exit_on_fixed_point ? b.d_state : nullptr;
+    unsigned long long *d_px = reinterpret_cast<unsigned long long *>(b.d_state + (((size_t)np * (1 + (size_t)passes * b.max_iter) + 1) & ~size_t(1)));
+    unsigned long long *d_px_count = ctx->profiling ? d_px : nullptr;
     bool first = true;
     int sweep_no = 0;
     OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
     for (int pass = 0; pass < passes; ++pass) {
         const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
         const bool last_pass = (pass == passes - 1);
+        if (pass > 0 && d_frozen) OBIA_HIP_TRY(hipMemsetAsync(d_frozen, 0, sizeof(int) * np, ctx->stream));   // a new pass starts unfrozen
         for (int it = 0; it < b.max_iter; ++it) {
             int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
             int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
+            int *d_changed = d_frozen ? b.d_state + (size_t)np * (1 + sweep_no) : nullptr;
+            // the last pre-pass sweep always runs: its colour means seed the main pass
+            const int force = (ignore_color && it == b.max_iter - 1) ? 1 : 0;
             ++sweep_no;
             hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
                                b.d_cent_prob, b.total_cent, b.CP, RQ, first ? 1 : 0, b.d_seed, b.d_acc, 1.0 / b.fscale,
-                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells);
+                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, d_frozen, d_changed, force);
             b.d_head_cur = head_cur;
             first = false;
             // the update after the very last sweep is never read: skip its accumulation
@@ -640,18 +682,24 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
             const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
             {
                 ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
-                if (!ignore_color) ctx->timing.assign_px += (double)b.total_pix;
+                unsigned long long *pxc = d_px_count ? d_px_count + (ignore_color ? 1 : 0) : nullptr;
                 switch (b.CP) {
-                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color); break;
-                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color); break;
-                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color); break;
-                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color); break;
+                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
+                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
+                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
+                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
                     default: set_error("bad CP"); return OBIA_E_INVALID;
                 }
             }
         }
     }
     OBIA_HIP_TRY(hipGetLastError());
+    if (d_px_count) {
+        unsigned long long h[2] = {0, 0};
+        OBIA_TRY(read_back(ctx, h, d_px_count, sizeof(h)));
+        ctx->timing.assign_px += (double)h[0];
+        ctx->timing.prepass_px += (double)h[1];
+    }
     return OBIA_OK;
 }
 

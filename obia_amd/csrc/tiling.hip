@@ -186,6 +186,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.masked = true;       // the tiler always hands a mask to slic (tiling.py:137-143): maskSLIC structure
     b.start_label = 1;
     b.max_iter = S.sp.max_num_iter;
+    b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
     long long off = 0, maxpix = 1;
     b.probs.resize(np);
     b.windows.resize(np);

@@ -46,7 +46,8 @@ class HipTilerEngine:
                                   max_num_iter=slic_kwargs.get("max_num_iter", 10),
                                   convert2lab=slic_kwargs.get("convert2lab", None),
                                   min_size_factor=slic_kwargs.get("min_size_factor", 0.5),
-                                  max_size_factor=slic_kwargs.get("max_size_factor", 3), start_label=1, normalize_bands=True)
+                                  max_size_factor=slic_kwargs.get("max_size_factor", 3), start_label=1, normalize_bands=True,
+                                  exit_on_fixed_point=slic_kwargs.get("exit_on_fixed_point", False))
         self.tp = _lib.TilingParams()
         self.tp.tile_size, self.tp.buffer, self.tp.white_order = int(tile_size), int(buffer), 1
         self.tp.crown_radius, self.tp.pixel_width, self.tp.pixel_height = float(crown_radius), float(pixel_size[0]), float(pixel_size[1])

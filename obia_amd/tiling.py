@@ -81,7 +81,7 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
                          enforce_connectivity=kwargs.get("enforce_connectivity", True),
                          min_size_factor=kwargs.get("min_size_factor", 0.5),
                          max_size_factor=kwargs.get("max_size_factor", 3), slic_zero=kwargs.get("slic_zero", False),
-                         start_label=1, normalize_bands=True)
+                         start_label=1, normalize_bands=True, exit_on_fixed_point=kwargs.get("exit_on_fixed_point", False))
     if white_order not in ("raster", "parity"):
         raise ValueError("white_order must be 'raster' or 'parity'")
     tp = _lib.TilingParams()

@@ -41,7 +41,8 @@ def test_param_structs_match_header(lib):
     lib.load().obia_slic_default_params(ctypes.byref(p))
     assert (p.n_segments, p.compactness, p.max_num_iter, p.convert2lab, p.enforce_connectivity) == (100, 10.0, 10, -1, 1)
     assert (p.min_size_factor, p.max_size_factor, p.slic_zero, p.start_label, p.normalize_bands) == (0.5, 3.0, 0, 1, 0)
-    assert ctypes.sizeof(lib.SlicParams) == 3 * 8 + 7 * 4 + 4      # 3 doubles, 7 int32, tail padding
+    assert ctypes.sizeof(lib.SlicParams) == 3 * 8 + 8 * 4          # 3 doubles, 8 int32
+    assert p.exit_on_fixed_point == 0
     assert ctypes.sizeof(lib.TilingParams) == 3 * 8 + 4 * 4
 
 

@@ -110,6 +110,24 @@ def test_slic_matches_oracle_bit_exact_when_centroids_agree(amd, oracle):
     assert np.array_equal(pre, o_pre)
 
 
+@pytest.mark.parametrize("name", ["c2s_256x256x4_c10", "c3s_384x384x8_c025", "c2s_256x256x4_c005", "mask_128x160x4_c10",
+                                  "quickstart_128x128x3", "iter3_100x120x4"])
+def test_exit_on_fixed_point_is_bit_identical(amd, name):
+    """Stopping once the centroid records repeat must give exactly the labels of all max_num_iter sweeps."""
+    from obia_amd.segmentation import slic
+    from obia_amd.tiling import create_tiled_segments
+    z, params = load(name)
+    raw = z["raw"].astype(np.float32)
+    mask = z["mask"] if "mask" in z.files else None
+    a = slic(raw, mask=mask, _normalize_bands=True, **kwargs_of(params))
+    b = slic(raw, mask=mask, _normalize_bands=True, exit_on_fixed_point=True, **kwargs_of(params))
+    assert np.array_equal(a, b)
+    kw = dict(tile_size=100, buffer=16, crown_radius=4, pixel_size=(1.0, 1.0), compactness=params["compactness"])
+    la, na = create_tiled_segments(raw, input_mask=mask, **kw)
+    lb, nb = create_tiled_segments(raw, input_mask=mask, exit_on_fixed_point=True, **kw)
+    assert na == nb and np.array_equal(la, lb)
+
+
 @pytest.mark.parametrize("shape,n_seg,comp", [((96, 96, 4), 576, 10.0), ((130, 70, 8), 1200, 0.5), ((64, 200, 3), 3000, 1.0)])
 def test_dense_seeds_take_the_direct_bin_path(amd, oracle, shape, n_seg, comp):
     """S = 2..4 pixels: a 64x64 tile meets hundreds of candidate centroids, more than the LDS slots of the sweep

@@ -27,7 +27,7 @@ for (H, W, C, n, comp) in [(4096, 4096, 4, 50000, 10.0), (4096, 4096, 8, 50000, 
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.time()
-        lab = slic(img, n_segments=n, compactness=comp, _normalize_bands=True)
+        lab = slic(img, n_segments=n, compactness=comp, _normalize_bands=True, exit_on_fixed_point=bool(int(os.environ.get('OBIA_FP', '0'))))
         torch.cuda.synchronize()
         dt = time.time() - t0
         t = ctx.timing()
