@@ -1,0 +1,108 @@
+"""Edge cases of the HIP path against the oracle: every band-count instantiation (CP = 4, 8, 12, 16), tiny and
+degenerate rasters, float64 / strided input, explicit n_segments and non-square pixels in the tiler, rasters smaller
+than one tile, masks that empty whole tiles."""
+import numpy as np
+import pytest
+
+from tests.metrics import adjusted_rand_index, label_disagreement
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def synth(H, W, C, seed=0, period=9.0):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    return np.stack([400 * np.sin(xx / (period + 2 * c)) * np.cos(yy / (period + 3 + c)) + 1000 + 50 * c + rs.normal(0, 20, (H, W))
+                     for c in range(C)], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("C", [1, 2, 5, 6, 9, 12, 13, 16])
+@pytest.mark.parametrize("comp", [10.0, 0.3])
+def test_every_band_count_vs_oracle(oracle, C, comp):
+    from obia_amd.segmentation import slic
+    from obia_amd.statistics import zonal_stats
+    raw = synth(150, 170, C, seed=C)
+    kw = dict(n_segments=80, compactness=comp, convert2lab=False)
+    lab = slic(raw, _normalize_bands=True, **kw)
+    ref, pre, _ = oracle.slic(oracle.normalize(raw), return_all=True, **kw)
+    got_pre = slic(torch.as_tensor(raw).cuda(), _normalize_bands=True, _stage="pre", **kw).cpu().numpy()
+    assert label_disagreement(got_pre, pre) <= 1e-4
+    assert adjusted_rand_index(lab, ref) >= 0.99
+    st = zonal_stats(raw, lab)
+    chk = oracle.zonal_stats_numpy(raw, lab)
+    assert np.array_equal(st["count"], chk["count"])
+    np.testing.assert_allclose(st["mean"], chk["mean"], rtol=1e-5)
+    np.testing.assert_allclose(st["variance"], chk["variance"], rtol=1e-5, atol=1e-6 * float(raw.max() - raw.min()) ** 2)
+    np.testing.assert_array_equal(st["min"], chk["min"].astype(np.float32))
+    np.testing.assert_array_equal(st["max"], chk["max"].astype(np.float32))
+
+
+def test_more_than_16_bands_is_rejected_loudly():
+    from obia_amd.segmentation import slic
+    with pytest.raises(NotImplementedError):
+        slic(synth(32, 32, 17), n_segments=4)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 4), (1, 37, 4), (41, 1, 3), (2, 3, 4), (5, 200, 8), (65, 65, 4)])
+def test_tiny_and_degenerate_shapes(oracle, shape):
+    from obia_amd.segmentation import slic
+    H, W, C = shape
+    raw = synth(H, W, C, seed=1)
+    if H * W == 1:
+        raw[0, 0] = np.arange(C)          # a single pixel is a constant band: normalisation is undefined
+        with pytest.raises(ValueError):
+            slic(raw, n_segments=1, _normalize_bands=True)
+        return
+    kw = dict(n_segments=max(1, H * W // 30), compactness=1.0, convert2lab=False)
+    lab = slic(raw, _normalize_bands=True, **kw)
+    ref = oracle.slic(oracle.normalize(raw), **kw)
+    assert lab.shape == (H, W)
+    assert adjusted_rand_index(lab, ref) >= 0.99 or np.array_equal(lab, ref)
+
+
+def test_float64_and_strided_inputs_match_contiguous_float32():
+    from obia_amd.segmentation import slic, create_segments
+    raw = synth(120, 140, 6)
+    a = slic(raw, n_segments=60, compactness=0.5, _normalize_bands=True)
+    b = slic(raw.astype(np.float64), n_segments=60, compactness=0.5, _normalize_bands=True)
+    planar = np.ascontiguousarray(raw.transpose(2, 0, 1)).transpose(1, 2, 0)     # band-planar strides, like obia's fancy-index copy
+    assert not planar.flags.c_contiguous
+    c = slic(planar, n_segments=60, compactness=0.5, _normalize_bands=True)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    sel = create_segments(raw, segmentation_bands=[4, 1, 2, 0], n_segments=60, compactness=0.5, convert2lab=False)
+    d = slic(raw[:, :, [4, 1, 2, 0]], n_segments=60, compactness=0.5, convert2lab=False, _normalize_bands=True)
+    assert np.array_equal(sel, d)
+
+
+def test_tiler_variants_vs_oracle(oracle):
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    img = synth(190, 260, 4, seed=5)
+    # raster smaller than one tile in one direction; explicit n_segments; non-square pixels (corner squares differ per axis)
+    for kw in (dict(tile_size=200, buffer=20, crown_radius=5, pixel_size=(1.0, 1.0)),
+               dict(tile_size=80, buffer=12, n_segments=40, pixel_size=(1.0, 1.0)),
+               dict(tile_size=90, buffer=10, crown_radius=3, pixel_size=(0.5, 2.0))):
+        ref, n_ref = tiler.create_tiled_segments(img, None, compactness=10.0, **kw)
+        lab, n = create_tiled_segments(img, compactness=10.0, **kw)
+        assert np.array_equal(lab == 0, ref == 0)
+        assert adjusted_rand_index(lab, ref) >= 0.99 and abs(n - n_ref) <= max(1, 0.01 * n_ref)
+    # a mask that removes whole tiles and leaves slivers
+    mask = np.zeros((190, 260), bool)
+    mask[5:60, 10:250] = True
+    mask[100:104, :] = True
+    kw = dict(tile_size=80, buffer=12, crown_radius=3, pixel_size=(1.0, 1.0))
+    ref, n_ref = tiler.create_tiled_segments(img, mask, compactness=10.0, **kw)
+    lab, n = create_tiled_segments(img, input_mask=mask, compactness=10.0, **kw)
+    assert (lab[~mask] == 0).all()
+    assert adjusted_rand_index(lab, ref) >= 0.99 and abs(n - n_ref) <= max(1, 0.03 * n_ref)
+
+
+def test_tile_with_constant_band_is_skipped_not_fatal():
+    """a nodata block (all zeros) makes normalize_band 0/0 in that tile: the reference's slic raises ValueError on
+    the NaNs and the tiler prints "empty tile" and goes on (tiling.py:149-150)"""
+    from obia_amd.tiling import create_tiled_segments
+    img = synth(160, 160, 4, seed=8)
+    img[:80, :80, 2] = 0.0
+    lab, n = create_tiled_segments(img, tile_size=80, buffer=8, crown_radius=3, pixel_size=(1.0, 1.0))
+    assert n > 0 and (lab[:70, :70] == 0).all() and (lab[90:, 90:] > 0).mean() > 0.95
