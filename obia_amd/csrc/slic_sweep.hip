@@ -328,20 +328,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         for (int bi = tid; bi < nbins; bi += NT) {
             int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
             while (cur >= 0) {
-                const int *irec = reinterpret_cast<const int *>(cent + (size_t)cur * RS);
-                const int y0 = irec[2], y1 = irec[3], x0 = irec[4], x1 = irec[5];
+                // one round trip per list node: the whole record and the link are requested together
+                const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
+                const float4 r0 = src[0], r1 = src[1];
+                float4 rc[CP / 4];
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) rc[q] = src[2 + q];
+                const int nxt = next[cur];
+                const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
+                const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
                 if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
                     const int slot = atomicAdd(&s_cnt, 1);
                     if (slot < MAXC) {
-                        const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
                         float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
-                        dh[0] = src[0]; dh[1] = src[1];
+                        dh[0] = r0; dh[1] = r1;
                         float4 *dc = reinterpret_cast<float4 *>(&s_col[slot][0]);
 #pragma unroll
-                        for (int q = 0; q < CP / 4; ++q) dc[q] = src[2 + q];
+                        for (int q = 0; q < CP / 4; ++q) dc[q] = rc[q];
                     }
                 }
-                cur = next[cur];
+                cur = nxt;
             }
         }
     }
