@@ -159,13 +159,20 @@ def main():
         del lab_a
         torch.cuda.synchronize()
         t1 = time.time()
+        px_eval = px_all = pre_ms = asg_ms = 0.0
         for _ in range(args.steps):
             lab_b, n_b = create_tiled_segments(img, input_mask=mask, **kw2)
+            tt = ctx.timing()
+            px_eval += tt["assign_px"] + tt["prepass_px"]
+            pre_ms += tt["prepass_ms"]
+            asg_ms += tt["assign_ms"]
             zonal_stats(img, lab_b, n_labels=n_b, ctx=ctx)
         torch.cuda.synchronize()
         d = (time.time() - t1) / args.steps
         return {"value": round(float(H) * W / d / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(d * 1e3, 3),
-                "labels_identical_to_full_sweeps": same}
+                "labels_identical_to_full_sweeps": same, "prepass_ms": round(pre_ms / args.steps, 3),
+                "assign_ms": round(asg_ms / args.steps, 3),
+                "pixel_sweeps_evaluated_per_step": round(px_eval / args.steps)}
 
     for _ in range(args.warmup):
         step()

@@ -513,6 +513,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     }
     // window steps, bins, tiles
     int cell_off = 0, tile_max = 0;
+    long long tiles_all = 0;
     for (int p = 0; p < np; ++p) {
         SlicProblem &P = b.probs[p];
         P.K = K[p];
@@ -530,10 +531,12 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         cell_off += (int)nc;
         P.tiles_x = cdiv(P.W, SWEEP_TW);
         P.tiles_y = cdiv(P.H, SWEEP_TH);
-        P.tile_off = 0;
         const int nt = P.tiles_x * P.tiles_y;
+        P.tile_off = (int)tiles_all;
+        tiles_all += nt;
         if (nt > tile_max) tile_max = nt;
     }
+    b.total_tiles_all = tiles_all > 0 ? tiles_all : 1;
     b.total_cells = cell_off > 0 ? cell_off : 1;
     b.total_tiles = tile_max;
     OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));

@@ -44,7 +44,8 @@ struct SlicBatch {
     int start_label = 1;
     int max_iter = 10;
     long long total_pix = 0;
-    int total_cent = 0, total_cells = 0, total_tiles = 0;
+    int total_cent = 0, total_cells = 0, total_tiles = 0;   // total_tiles: largest tile count of one problem (grid.x)
+    long long total_tiles_all = 0;                          // sum over problems (per-tile state of exit_on_fixed_point)
     std::vector<SlicProblem> probs;    // host copy
     std::vector<SrcWindow> windows;
     // device arrays (arena)
@@ -61,7 +62,6 @@ struct SlicBatch {
     unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
     double fscale = 1.0;
     bool exit_on_fixed_point = false;
-    int *d_state = nullptr;            // [nprob] frozen flags, then [2*max_iter][nprob] per-sweep `changed` flags, then pixel counter
 };
 
 // Feature preparation for every problem of the batch: per-band min/max of its window, then

@@ -56,12 +56,10 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
                                                         int *__restrict__ next, int *__restrict__ head_other,
-                                                        int total_cells, const int *__restrict__ frozen,
-                                                        int *__restrict__ changed, int force) {
-    // Fixed-point detection (exit_on_fixed_point): `changed[p]` is raised when any centroid record of problem p
-    // differs from the record of the previous sweep; a problem none of whose records moved is frozen by the sweep
-    // kernel and skipped from then on.  `force` re-runs a frozen problem from its standing records (last pre-pass
-    // sweep: its colour means seed the main pass).
+                                                        int total_cells, int *__restrict__ bin_stamp, int sweep_id) {
+    // exit_on_fixed_point: a centroid whose record differs from the previous sweep's stamps the bin it leaves and the
+    // bin it enters with the sweep number; the sweep kernel skips a tile none of whose bins was stamped since the tile
+    // was last evaluated (same candidate records => same labels, same partial sums, replayed from the tile's cache).
     // the bin heads are double-buffered: while this sweep fills `head`, the buffer of the NEXT sweep is reset here
     // (saves one memset launch per sweep)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
@@ -73,16 +71,10 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     if (k - P.cent_off >= P.K) return;
     const int RS = CENT_REC + CP;
     float *rec = cent + (size_t)k * RS;
-    const bool is_frozen = frozen && frozen[p];
-    if (is_frozen && !force) return;
     float cy, cx;
     bool moved = false;
-    if (is_frozen) {            // forced sweep of a frozen problem: keep the standing record, only re-bin it
-        cy = rec[0]; cx = rec[1];
-        unsigned long long *a = acc + (size_t)k * RQ;
-        for (int c = 0; c < CP + 2; ++c) a[c] = 0;
-        moved = true;
-    } else if (first) {
+    const float old_cy = rec[0], old_cx = rec[1];
+    if (first) {
         cy = seed[2 * (size_t)k];
         cx = seed[2 * (size_t)k + 1];
         for (int c = 0; c < CP; ++c) rec[CENT_REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
@@ -105,9 +97,12 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
         a[CP] = 0; a[CP + 1] = 0;
         moved |= __float_as_uint(cy) != __float_as_uint(rec[0]) || __float_as_uint(cx) != __float_as_uint(rec[1]);
     }
-    // lanes of one wave can belong to different problems; test before the atomic so that a problem whose flag is
-    // already up costs a cached read, not an atomic per centroid
-    if (changed && moved && __hip_atomic_load(&changed[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&changed[p], 1);
+    if (bin_stamp && moved && !first && old_cy == old_cy && old_cx == old_cx) {   // the bin it leaves
+        int oby = (int)(old_cy / (float)P.sy), obx = (int)(old_cx / (float)P.sx);
+        oby = oby < 0 ? 0 : (oby >= P.ncy ? P.ncy - 1 : oby);
+        obx = obx < 0 ? 0 : (obx >= P.ncx ? P.ncx - 1 : obx);
+        bin_stamp[P.cell_off + oby * P.ncx + obx] = sweep_id;
+    }
     rec[0] = cy; rec[1] = cx;
     int *irec = reinterpret_cast<int *>(rec);
     irec[6] = k; irec[7] = 0;
@@ -126,6 +121,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
     bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
     next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+    if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
 }
 
 // double -> 64-bit fixed point, round to nearest even.  |v * fscale| < 2^51 (the scale is chosen for that in
@@ -239,12 +235,13 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 }
 
 // K2: the sweep.  grid = (max tiles per problem, nprob).
-template <int CP, bool MASKED, bool IGNORE_COLOR>
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
     int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,
-    int start_label, double fscale, int *__restrict__ frozen, const int *__restrict__ changed, int force,
+    int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
+    int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter) {
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
@@ -252,13 +249,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const SlicProblem P = probs[blockIdx.y];
     const int tile = blockIdx.x;
     if (tile >= P.tiles_x * P.tiles_y) return;
-    if (frozen && !force) {
-        // exit_on_fixed_point: this sweep starts from records bit-identical to the previous sweep's (no centroid of
-        // the problem moved): it would reproduce the same labels and the same sums.  Freeze the problem.
-        if (frozen[blockIdx.y]) return;
-        if (!changed[blockIdx.y]) { if (threadIdx.x == 0) frozen[blockIdx.y] = 1; return; }
-    }
-    if (px_counter && tile == 0 && threadIdx.x == 0) atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
     constexpr int RS = CENT_REC + CP;
     constexpr int AQ = CP + 1;                  // qwords of an LDS accumulator: colours, then one packed word
                                                 //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 128x64 tile: n <= 8192,
@@ -270,17 +260,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     __shared__ unsigned long long s_acc[MAXC][AQ];
     __shared__ double s_tf[NT / 64][CP][65];    // 65: row stride that keeps the transposed reads conflict-free
     __shared__ int s_tkey[NT / 64][64];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt, s_uncacheable;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ty0 = (tile / P.tiles_x) * SWEEP_TH, tx0 = (tile % P.tiles_x) * SWEEP_TW;
     const int ty1 = min(ty0 + SWEEP_TH, P.H), tx1 = min(tx0 + SWEEP_TW, P.W);
 
     STAMP_DECL
-    for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-
     // ---- wave geometry; the features of the wave's FIRST footprint are requested before staging, so their HBM
     // latency overlaps the dependent bin -> record loads of the staging phase ---------------------------------------
     const float w = P.spatial_w;
@@ -313,18 +299,53 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             }
         }
     };
-    if (wave_active) fetch(tx0);
+    if (!FIXPT && wave_active) fetch(tx0);
+    constexpr int GQ = CP + 2;   // global record / cache entry: colours, n | sum_y << 32, sum_x
+    const int tile_id = P.tile_off + tile;
+    // bins whose centroids can reach the tile: candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with
+    // y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H)) that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel
+    // of slack covers float rounding of the binning.
+    int by_lo = (ty0 - 2 * P.sy - 2) / P.sy; if (ty0 - 2 * P.sy - 2 < 0) by_lo = 0;
+    int by_hi = (ty1 + 2 * P.sy + 1) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
+    int bx_lo = (tx0 - 2 * P.sx - 2) / P.sx; if (tx0 - 2 * P.sx - 2 < 0) bx_lo = 0;
+    int bx_hi = (tx1 + 2 * P.sx + 1) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
+    const int nbw = bx_hi - bx_lo + 1;
+    const int nbins = (by_hi - by_lo + 1) * nbw;
+    if (FIXPT) {
+        // exit_on_fixed_point: has any bin that can feed this tile been stamped since the tile was last evaluated?
+        const int lp = use_cache ? tile_lp[tile_id] : 0;
+        int dirty = lp <= 0;
+        if (!dirty)
+            for (int bi = tid; bi < nbins; bi += NT)
+                dirty |= bin_stamp[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw] > lp;
+        if (!__syncthreads_or(dirty)) {
+            // same candidate records as when the cache was written: same labels (already in place), same partial
+            // sums -- replay them (cache_k[.][0] holds the slot count, -1 marks a slot nothing landed on)
+            if (accumulate) {
+                const int *ck = cache_k + (size_t)tile_id * (MAXC + 1);
+                const unsigned long long *cq = cache_q + (size_t)tile_id * MAXC * GQ;
+                const int ne = ck[0];
+                for (int i = tid; i < ne * GQ; i += NT) {
+                    const int e = i / GQ, q = i - e * GQ;
+                    const int k = ck[1 + e];
+                    if (k < 0 || (q < CP && !accum_color)) continue;
+                    atomicAdd(&acc[(size_t)k * RQ + q], cq[(size_t)e * GQ + q]);
+                }
+            }
+            return;
+        }
+        if (px_counter && tid == 0) atomicAdd(&px_counter[tile & 255], (unsigned long long)(ty1 - ty0) * (unsigned long long)(tx1 - tx0));
+    } else if (px_counter && tile == 0 && tid == 0) {
+        atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
+    }
+    for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
+    if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
+    __syncthreads();
+
+    if (FIXPT && wave_active) fetch(tx0);
 
     // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
-    // candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H))
-    // that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel of slack covers float rounding of the binning.
     {
-        int by_lo = (ty0 - 2 * P.sy - 2) / P.sy; if (ty0 - 2 * P.sy - 2 < 0) by_lo = 0;
-        int by_hi = (ty1 + 2 * P.sy + 1) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
-        int bx_lo = (tx0 - 2 * P.sx - 2) / P.sx; if (tx0 - 2 * P.sx - 2 < 0) bx_lo = 0;
-        int bx_hi = (tx1 + 2 * P.sx + 1) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
-        const int nbw = bx_hi - bx_lo + 1;
-        const int nbins = (by_hi - by_lo + 1) * nbw;
         for (int bi = tid; bi < nbins; bi += NT) {
             int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
             while (cur >= 0) {
@@ -509,6 +530,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 // no window reaches this pixel: `nearest` keeps the previous sweep's value (it is only initialised
                 // once, before the loop) and the pixel is accumulated under it
                 const int prev = labels[pix];
+                if (FIXPT) s_uncacheable = 1;   // this tile's result depends on the previous labels: never replay it
                 if (prev >= start_label && accumulate) {
                     double one[CP];
 #pragma unroll
@@ -599,19 +621,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     if (!accumulate) { STAMP_FLUSH return; }
     __syncthreads();
     // ---- LDS accumulators -> global records: consecutive lanes write consecutive qwords of one 128-B record -----------
-    constexpr int GQ = CP + 2;   // global record: colours, n | sum_y << 32, sum_x
+    // (with exit_on_fixed_point the same values are kept, slot by slot, as the tile's cache for the sweeps that replay them)
+    const bool keep = FIXPT && !s_uncacheable;
+    int *ck = keep ? cache_k + (size_t)tile_id * (MAXC + 1) : nullptr;
+    unsigned long long *cq = keep ? cache_q + (size_t)tile_id * MAXC * GQ : nullptr;
     for (int i = tid; i < nc * GQ; i += NT) {
         const int slot = i / GQ, q = i - slot * GQ;
         const unsigned long long pw = s_acc[slot][CP];
         const unsigned long long n = pw & 0xffffull;
+        if (FIXPT && keep && q == 0) ck[1 + slot] = n ? __float_as_int(s_hdr[slot][6]) : -1;
         if (n == 0ull) continue;   // nothing landed on this centroid
         const int k = __float_as_int(s_hdr[slot][6]);
         unsigned long long v;
-        if (q < CP) { if (!accum_color) continue; v = s_acc[slot][q]; }
+        if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][q] : 0ull; }
         else if (q == CP) v = n | ((((pw >> 16) & 0xffffffull) + n * (unsigned long long)ty0) << 32);
         else v = (pw >> 40) + n * (unsigned long long)tx0;
+        if (FIXPT && keep) cq[(size_t)slot * GQ + q] = v;
+        if (FIXPT && q < CP && !accum_color) continue;
         atomicAdd(&acc[(size_t)k * RQ + q], v);
     }
+    if (keep && tid == 0) { ck[0] = nc; tile_lp[tile_id] = sweep_id; }
     STAMP(7)   // barrier + flush
     STAMP_FLUSH
 }
@@ -623,20 +652,28 @@ extern "C" void obia_debug_stamps(unsigned long long *out16, int reset) {
 }
 #endif
 
+struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; null when the option is off)
+    int *bin_stamp = nullptr, *tile_lp = nullptr, *cache_k = nullptr;
+    unsigned long long *cache_q = nullptr;
+};
+
 template <int CP>
-static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color, int *frozen,
-                          const int *changed, int force, unsigned long long *px_counter) {
+static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color,
+                          const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
     dim3 grid(b.total_tiles, b.nprob);
     static const int ablate = getenv("OBIA_ABLATE") ? atoi(getenv("OBIA_ABLATE")) : 0;   // timing experiments only
     if (ablate & 1) accumulate = 0;
     const int RQ = acc_record_qwords(CP);
-#define LAUNCH_ASSIGN(M, I)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
+#define LAUNCH_ASSIGN_(M, I, F)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
-                       accum_color, b.start_label, b.fscale, frozen, changed, force, px_counter)
+                       accum_color, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,   \
+                       use_cache, px_counter)
+#define LAUNCH_ASSIGN(M, I) do { if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true); else LAUNCH_ASSIGN_(M, I, false); } while (0)
     if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
     else LAUNCH_ASSIGN(false, false);
 #undef LAUNCH_ASSIGN
+#undef LAUNCH_ASSIGN_
 }
 
 __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
@@ -655,56 +692,61 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
     const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
     const int RQ = acc_record_qwords(b.CP);
-    const int np = b.nprob;
-    // state: frozen[np] | changed[passes*max_iter][np] | 2 pixel counters (colour sweeps, pre-pass sweeps) as u64
-    const size_t n_state = (size_t)np * (1 + (size_t)passes * b.max_iter) + 4;
-    b.d_state = ctx->arena.get<int>(n_state);
-    if (!b.d_state) return OBIA_E_NOMEM;
-    OBIA_HIP_TRY(hipMemsetAsync(b.d_state, 0, sizeof(int) * n_state, ctx->stream));
-    int *d_frozen = b.exit_on_fixed_point ? b.d_state : nullptr;
-    unsigned long long *d_px = reinterpret_cast<unsigned long long *>(b.d_state + (((size_t)np * (1 + (size_t)passes * b.max_iter) + 1) & ~size_t(1)));
-    unsigned long long *d_px_count = ctx->profiling ? d_px : nullptr;
+    Arena &A = ctx->arena;
+    // pixel counters (profiling): 256 slots each for the colour sweeps and the pre-pass sweeps, summed on the host
+    unsigned long long *d_px = ctx->profiling ? A.get<unsigned long long>(512) : nullptr;
+    if (ctx->profiling && !d_px) return OBIA_E_NOMEM;
+    if (d_px) OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 512, ctx->stream));
+    FixedPointState fp;
+    if (b.exit_on_fixed_point) {
+        const size_t nt = (size_t)b.total_tiles_all;
+        fp.bin_stamp = A.get<int>((size_t)b.total_cells);
+        fp.tile_lp = A.get<int>(nt);
+        fp.cache_k = A.get<int>(nt * (MAXC + 1));
+        fp.cache_q = A.get<unsigned long long>(nt * MAXC * (size_t)(b.CP + 2));
+        if (!fp.bin_stamp || !fp.tile_lp || !fp.cache_k || !fp.cache_q) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(fp.bin_stamp, 0, sizeof(int) * (size_t)b.total_cells, ctx->stream));
+        OBIA_HIP_TRY(hipMemsetAsync(fp.tile_lp, 0, sizeof(int) * nt, ctx->stream));
+    }
     bool first = true;
     int sweep_no = 0;
     OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
     for (int pass = 0; pass < passes; ++pass) {
         const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
         const bool last_pass = (pass == passes - 1);
-        if (pass > 0 && d_frozen) OBIA_HIP_TRY(hipMemsetAsync(d_frozen, 0, sizeof(int) * np, ctx->stream));   // a new pass starts unfrozen
         for (int it = 0; it < b.max_iter; ++it) {
             int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
             int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
-            int *d_changed = d_frozen ? b.d_state + (size_t)np * (1 + sweep_no) : nullptr;
-            // the last pre-pass sweep always runs: its colour means seed the main pass
-            const int force = (ignore_color && it == b.max_iter - 1) ? 1 : 0;
-            ++sweep_no;
+            ++sweep_no;   // sweep ids start at 1
             hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
                                b.d_cent_prob, b.total_cent, b.CP, RQ, first ? 1 : 0, b.d_seed, b.d_acc, 1.0 / b.fscale,
-                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, d_frozen, d_changed, force);
+                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
             b.d_head_cur = head_cur;
             first = false;
             // the update after the very last sweep is never read: skip its accumulation
             const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
             const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
+            // the last pre-pass sweep is the only one of its pass that folds colours (they seed the main pass): the
+            // caches written by the earlier pre-pass sweeps hold no colour sums, so it evaluates every tile
+            const int use_cache = (ignore_color && it == b.max_iter - 1) ? 0 : 1;
             {
                 ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
-                unsigned long long *pxc = d_px_count ? d_px_count + (ignore_color ? 1 : 0) : nullptr;
+                unsigned long long *pxc = d_px ? d_px + (ignore_color ? 256 : 0) : nullptr;
                 switch (b.CP) {
-                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
-                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
-                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
-                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, d_frozen, d_changed, force, pxc); break;
+                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
                     default: set_error("bad CP"); return OBIA_E_INVALID;
                 }
             }
         }
     }
     OBIA_HIP_TRY(hipGetLastError());
-    if (d_px_count) {
-        unsigned long long h[2] = {0, 0};
-        OBIA_TRY(read_back(ctx, h, d_px_count, sizeof(h)));
-        ctx->timing.assign_px += (double)h[0];
-        ctx->timing.prepass_px += (double)h[1];
+    if (d_px) {
+        unsigned long long h[512];
+        OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
+        for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
     }
     return OBIA_OK;
 }

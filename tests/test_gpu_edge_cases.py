@@ -106,3 +106,34 @@ def test_tile_with_constant_band_is_skipped_not_fatal():
     img[:80, :80, 2] = 0.0
     lab, n = create_tiled_segments(img, tile_size=80, buffer=8, crown_radius=3, pixel_size=(1.0, 1.0))
     assert n > 0 and (lab[:70, :70] == 0).all() and (lab[90:, 90:] > 0).mean() > 0.95
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("max_iter", [10, 25])
+def test_fixed_point_tile_cache_skips_work_and_keeps_labels(masked, max_iter):
+    """exit_on_fixed_point replays the cached partial sums of every 64x64 tile whose candidate centroids stood still.
+    On a raster of flat fields most tiles converge within a few sweeps: the option must evaluate fewer pixel-sweeps
+    (so the replay path really ran) and still return exactly the labels of the full sweeps."""
+    from obia_amd import _lib
+    from obia_amd.segmentation import slic
+    rs = np.random.RandomState(5)
+    H, W, C = 700, 900, 4
+    fields = rs.uniform(0, 1000, (7, 9, C)).astype(np.float32)
+    raw = np.repeat(np.repeat(fields, 100, 0), 100, 1)[:H, :W].copy()
+    raw[:350] += rs.normal(0, 5, (350, W, C)).astype(np.float32)       # the upper half keeps moving
+    mask = None
+    if masked:
+        mask = np.ones((H, W), np.uint8)
+        mask[100:180, 200:420] = 0
+        mask[:, 860:] = 0
+    ctx = _lib.Context(0)
+    ctx.set_profiling(True)
+    kw = dict(n_segments=600, compactness=20.0, max_num_iter=max_iter, convert2lab=False, mask=mask, _normalize_bands=True, ctx=ctx)
+    full = slic(raw, **kw)
+    t_full = ctx.timing()
+    fast = slic(raw, exit_on_fixed_point=True, **kw)
+    t_fast = ctx.timing()
+    assert np.array_equal(full, fast)
+    px_full = t_full["assign_px"] + t_full["prepass_px"]
+    px_fast = t_fast["assign_px"] + t_fast["prepass_px"]
+    assert px_fast < 0.9 * px_full, (px_fast, px_full)
