@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+typedef float float2v __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(float *out, int iters) {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
@@ -13,6 +14,16 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters) {
             a4 = a4 * b + c; a5 = a5 * b + c; a6 = a6 * b + c; a7 = a7 * b + c;
         } else if (MODE == 1) {   // separate mul + add (contraction off), like the distance arithmetic
             a0 = a0 * b; a0 = a0 + c; a1 = a1 * b; a1 = a1 + c; a2 = a2 * b; a2 = a2 + c; a3 = a3 * b; a3 = a3 + c;
+        } else if (MODE == 3 || MODE == 4) {   // packed f32: 4 pairs, mul + add (MODE 4: second operand broadcast via op_sel)
+            float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+            const float2v bb = {b, b}, cc = {c, c};
+            if (MODE == 3) {
+                p0 = p0 * bb; p0 = p0 + cc; p1 = p1 * bb; p1 = p1 + cc; p2 = p2 * bb; p2 = p2 + cc; p3 = p3 * bb; p3 = p3 + cc;
+            } else {
+                const float2v v = {a0, a0};
+                p0 = p0 * bb; p0 = p0 - v; p1 = p1 * bb; p1 = p1 - v; p2 = p2 * bb; p2 = p2 - v; p3 = p3 * bb; p3 = p3 - v;
+            }
+            a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
         } else {   // compare + select mix
             a0 = (a0 < a1) ? a2 : a0; a1 = (a1 < a2) ? a3 : a1; a2 = (a2 < a3) ? a4 : a2; a3 = (a3 < a4) ? a5 : a3;
             a4 = a4 * b + c; a5 = a5 * b + c; a6 = a6 * b + c; a7 = a7 * b + c;
@@ -42,5 +53,7 @@ int main() {
     run<0>("8 independent v_fma_f32", 8);
     run<1>("mul+add pairs (no fma)", 8);
     run<2>("cmp/cndmask + fma mix", 12);
+    run<3>("v_pk_mul/add_f32 (8 instr)", 8);
+    run<4>("v_pk mul/sub, op_sel bcast", 8);
     return 0;
 }
