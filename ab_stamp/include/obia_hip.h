@@ -1,0 +1,199 @@
+/*
+ * obia_hip.h -- C ABI of libobia_hip.so: the MI355X (gfx950) tiled-SLIC + zonal-statistics path
+ * that drops in behind obia.segmentation.segment(method="slic") and
+ * obia.utils.tiling.create_tiled_segments.
+ *
+ * The reference (iosefa/obia) is pure Python and has no FFI of its own; the boundary is defined by
+ * its call sites.  Each entry point below names the reference interface it replaces (file:line
+ * under /root/reference).  Plain pointers and sizes only -- no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative OBIA_E_* code on failure;
+ *     obia_last_error() returns a thread-local message for the last failure.  No C++ exception
+ *     crosses this ABI.
+ *   - one obia_ctx per (device, stream).  A context is NOT thread-safe; independent contexts may
+ *     run concurrently.  A context owns a growing device workspace that is reused across calls
+ *     (no hipMalloc in the steady state).
+ *   - `*_dev` functions take DEVICE pointers valid on the context's device and enqueue work on
+ *     the context's stream; they synchronise the stream only where they return a host scalar.
+ *     Functions without the suffix take HOST pointers and do H2D / D2H themselves.
+ *   - images are (H, W, C) float32, band-interleaved, C-contiguous -- the layout of
+ *     obia.handlers.geotif.Image.img_data (geotif.py:100, tiling.py:47).  Labels are int32.
+ */
+#ifndef OBIA_HIP_H
+#define OBIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBIA_ABI_VERSION 1
+
+#define OBIA_OK 0
+#define OBIA_E_INVALID (-1)     /* bad argument (Python side raises ValueError)                     */
+#define OBIA_E_HIP (-2)         /* HIP runtime error                                                */
+#define OBIA_E_NOMEM (-3)
+#define OBIA_E_UNSUPPORTED (-4) /* valid in the reference, not implemented here (NotImplementedError) */
+#define OBIA_E_EMPTY (-5)       /* empty / fully masked input (the reference raises ValueError; the tiler
+                                   catches it per tile, tiling.py:149-150)                          */
+#define OBIA_E_NONFINITE (-6)   /* constant band (0/0 in normalize_band) or NaN/inf input           */
+
+typedef struct obia_ctx obia_ctx;
+
+int obia_abi_version(void);
+const char *obia_last_error(void);
+
+/* Create a context on `device_id` with its own HIP stream / on a caller-owned hipStream_t. */
+obia_ctx *obia_create(int device_id);
+obia_ctx *obia_create_on_stream(int device_id, void *hip_stream);
+void obia_destroy(obia_ctx *ctx);
+int obia_synchronize(obia_ctx *ctx);
+/* bytes of device workspace currently held by the context */
+int64_t obia_workspace_bytes(obia_ctx *ctx);
+
+/* SLIC parameters: the keyword arguments obia forwards untouched to skimage.segmentation.slic
+ * (segment.py:86 -> segment_boundaries.py:51; tiling.py:137-143). */
+typedef struct obia_slic_params {
+    double compactness;            /* doubles: Python floats, so 1/compactness and int(factor*size)   */
+    double min_size_factor;        /* round exactly as in the reference                               */
+    double max_size_factor;
+    int32_t n_segments;
+    int32_t max_num_iter;          /* scikit-image `max_num_iter` (`max_iter` before 0.19)            */
+    int32_t convert2lab;           /* -1 auto (Lab iff C == 3), 0, 1                                  */
+    int32_t enforce_connectivity;
+    int32_t slic_zero;             /* 1 -> OBIA_E_UNSUPPORTED in this version                         */
+    int32_t start_label;           /* 0 or 1                                                          */
+    int32_t normalize_bands;       /* 1: apply normalize_band (segment_boundaries.py:11-16,32-33) to
+                                      every band before segmenting, as create_segments does           */
+    int32_t exit_on_fixed_point;   /* 1: stop sweeping a raster / tile as soon as a sweep starts from centroid
+                                      records that are bit-identical to those of the previous sweep: every
+                                      later sweep would reproduce the same labels and the same centroids, so
+                                      the result is bit-identical to running all max_num_iter sweeps (the
+                                      reference's own `if change == 0: break` intends this but never fires).
+                                      0: always run max_num_iter sweeps.  Default 0.                    */
+} obia_slic_params;
+
+void obia_slic_default_params(obia_slic_params *p);
+
+/* ---- B1: segmentation operator --------------------------------------------------------------------
+ * Replaces  `segments = slic(img_to_segment, **kwargs)`  (segment_boundaries.py:48-51) together with
+ * the per-band normalisation in front of it (segment_boundaries.py:32-33, when normalize_bands=1).
+ *   img        (H,W,C) float32; not modified
+ *   mask       (H,W) uint8, nullable; 0 = excluded (labelled start_label-1)
+ *   labels_out (H,W) int32: consecutive labels from start_label (after connectivity enforcement)
+ *   n_labels_out  host int: number of labels produced
+ * With a mask the maskSLIC structure of the reference is kept (spatial-only pre-pass, then the
+ * main pass) but seeding uses the deterministic masked-grid rule documented in DESIGN.md.            */
+int obia_slic_f32(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, const uint8_t *mask,
+                  const obia_slic_params *params, int32_t *labels_out, int *n_labels_out);
+int obia_slic_f32_dev(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, const uint8_t *mask,
+                      const obia_slic_params *params, int32_t *labels_out, int *n_labels_out);
+
+/* Stage-level entry points (device pointers), used by the parity tests to compare each stage with
+ * the oracle: labels before connectivity enforcement, and connectivity enforcement alone
+ * (restates _enforce_label_connectivity_cython, slic_superpixels.py:320-328).                        */
+int obia_slic_assign_only_f32_dev(obia_ctx *ctx, const float *img_hwc, int H, int W, int C,
+                                  const uint8_t *mask, const obia_slic_params *params,
+                                  int32_t *labels_pre_out, int *n_centroids_out);
+int obia_enforce_connectivity_i32_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W,
+                                      int min_size, int max_size, int start_label,
+                                      int32_t *labels_out, int *n_labels_out);
+
+/* ---- B2: zonal-statistics operator ----------------------------------------------------------------
+ * Replaces the per-segment loop crop_image_to_bbox -> mask_image_with_polygon ->
+ * calculate_spectral_stats (segment_statistics.py:475-491, :143-172; utils/utils.py:37-67), batched
+ * over all segments: "pixels inside polygon p" == "pixels carrying label p" (SURVEY.md 3.3).
+ *   raw     (H,W,C) float32 RAW (un-normalised) raster
+ *   labels  (H,W) int32; labels outside [start_label, start_label+n_labels) are ignored
+ *   bands   n_bands band indices (nullable = all C bands)
+ *   outputs: count[n_labels] int64; mean/var [n_labels*n_bands] float64 (var: ddof 0);
+ *            min/max [n_labels*n_bands] float32.  Empty label -> NaN (segment_statistics.py:150-162). */
+int obia_zonal_stats_f32(obia_ctx *ctx, const float *raw_hwc, const int32_t *labels_hw, int H, int W, int C,
+                         const int32_t *bands, int n_bands, int n_labels, int start_label,
+                         int64_t *count_out, double *mean_out, double *var_out, float *min_out, float *max_out);
+int obia_zonal_stats_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_t *labels_hw, int H, int W, int C,
+                             const int32_t *bands, int n_bands, int n_labels, int start_label,
+                             int64_t *count_out, double *mean_out, double *var_out, float *min_out, float *max_out);
+
+/* ---- B1': quickshift (the alternate method of create_segments, segment_boundaries.py:48-49) ------------------
+ * Replaces `segments = quickshift(img_to_segment, **kwargs)`: skimage _quickshift.py:59-74 + _quickshift_cy.pyx.
+ * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64
+ * noise scikit-image adds to the densities, RandomState(random_seed).normal(scale=1e-5) -- generated by the host
+ * (NumPy's legacy stream is stable); NULL = no noise.  labels_out: consecutive ids from 0 in ascending order of the
+ * root pixel (np.unique(...)[1]).  kernel_size <= 5 and 1, 3 or 4 bands in this version.                          */
+int obia_quickshift_f32(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
+                        double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                        int32_t *labels_out, int *n_labels_out);
+int obia_quickshift_f32_dev(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
+                            double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                            int32_t *labels_out, int *n_labels_out);
+
+/* ---- B3: tiled driver ------------------------------------------------------------------------------
+ * Replaces the tile loops of create_tiled_segments (tiling.py:103-291) on label rasters: pass 1
+ * "black" checkerboard tiles on exact windows, pass 2 "white" tiles on windows grown by `buffer`,
+ * existing segments wholly inside a grown window (minus the two bottom corner squares) are erased
+ * and re-segmented, straddling ones are kept and masked out (tiling.py:205-260); ids 1..N at the
+ * end (tiling.py:289-290).  n_segments per tile: params->n_segments scaled by valid area if > 0,
+ * else the reference's crown rule round(valid_px * pixel_area / (pi * crown_radius^2))
+ * (tiling.py:126-135).
+ *   row0/rows: this call processes tile rows whose first pixel row lies in [row0, row0+rows) of the
+ *   full H-row raster (multi-GPU slabs); pass 0,H for the whole raster.                               */
+typedef struct obia_tiling_params {
+    double crown_radius;
+    double pixel_width;    /* |geotransform[1]| */
+    double pixel_height;   /* |geotransform[5]| */
+    int32_t tile_size;
+    int32_t buffer;
+    int32_t white_order;   /* 0: white tiles in the reference's raster order (tile-row by tile-row);
+                              1: two parity classes of tile rows (even rows, then odd rows) -- the order
+                              the sharded driver needs so that neighbouring slabs never touch the same seam
+                              at once; both orders give the same kind of result, they differ in who wins
+                              the 2*buffer x 2*buffer corner overlaps of diagonal white neighbours          */
+    int32_t reserved;
+} obia_tiling_params;
+
+int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img_hwc, const uint8_t *mask, int H, int W, int C,
+                            const obia_tiling_params *tiling, const obia_slic_params *params,
+                            int32_t *labels_out, int64_t *n_segments_out);
+int obia_tiled_slic_f32(obia_ctx *ctx, const float *img_hwc, const uint8_t *mask, int H, int W, int C,
+                        const obia_tiling_params *tiling, const obia_slic_params *params,
+                        int32_t *labels_out, int64_t *n_segments_out);
+
+/* ---- B3, sharded: the same tile loops as a session, for slabs of a raster spread over several GPUs --------
+ * The caller holds rows [row0, row0 + H_local) of a (H_global, W) raster on this GPU: its slab plus the halo
+ * rows its white windows reach (`buffer` rows, +1 label row so that "segment continues beyond the halo" can be
+ * seen).  labels_local (same rows) is the persistent label raster G of the session: provisional ids 1..next_id-1,
+ * 0 = no segment.  Between passes the host exchanges halo rows of G with the neighbouring ranks (RCCL send/recv)
+ * and registers the segments it imported with obia_tiler_set_segments (their pixel counts as seen locally;
+ * 0xffffffff for a segment that continues beyond the halo and can therefore never be "within" a window).
+ * tile rows are GLOBAL indices; row_parity -1 = all rows, 0/1 = rows of that parity (white_order 1).
+ * The context must not be used for other calls while a session is open.                                         */
+typedef struct obia_tiler obia_tiler;
+obia_tiler *obia_tiler_create(obia_ctx *ctx, const float *img_local, const uint8_t *mask_local, int H_local, int W, int C,
+                              int H_global, int row0, const obia_tiling_params *tiling, const obia_slic_params *params,
+                              int32_t *labels_local, int extra_ids);
+void obia_tiler_destroy(obia_tiler *t);
+int obia_tiler_run(obia_tiler *t, int white, int tile_row_lo, int tile_row_hi, int row_parity);
+int obia_tiler_next_id(obia_tiler *t);
+int obia_tiler_set_segments(obia_tiler *t, int first_id, int count, const uint32_t *sizes_dev);
+/* alive flags of the provisional ids [0, count): 1 = the segment exists, 0 = dropped (it was `within` a white
+ * window) or never created.  A rank that dropped a neighbour's segment tells the owner, which clears the flag. */
+int obia_tiler_get_alive(obia_tiler *t, uint8_t *alive_out_dev, int count);
+int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count);
+int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
+
+/* ---- measurement hooks ------------------------------------------------------------------------------
+ * Time of the most recent call's kernels by class, measured with HIP events on the context's
+ * stream (bench.py's roofline leg).  `what`: 0 = SLIC colour sweeps (sum of launches, ms), 1 = number of
+ * those launches, 2 = feature preparation, 3 = connectivity, 4 = zonal statistics, 5 = whole call,
+ * 6 = maskSLIC spatial-only pre-pass sweeps (ms), 7 = pixels actually processed by the launches of 0
+ * (sum; tiles skipped by exit_on_fixed_point are not counted), 8 = the same for the pre-pass launches.    */
+int obia_set_profiling(obia_ctx *ctx, int enabled);
+double obia_last_timing(obia_ctx *ctx, int what);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBIA_HIP_H */

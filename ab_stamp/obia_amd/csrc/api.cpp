@@ -1,0 +1,220 @@
+// api.cpp -- the C ABI of libobia_hip.so (include/obia_hip.h): argument checking and orchestration of
+// the kernels for the single-raster operators B1 (SLIC) and B2 (zonal statistics).
+#include "slic.hpp"
+
+#include <cmath>
+
+using namespace obia;
+
+namespace {
+
+int check_ctx(obia_ctx *ctx) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", ctx->device); return OBIA_E_HIP; }
+    return OBIA_OK;
+}
+
+int check_slic_args(const float *img, int H, int W, int C, const obia_slic_params *p) {
+    if (!img || !p) { set_error("null image or params"); return OBIA_E_INVALID; }
+    if (H <= 0 || W <= 0 || C <= 0) { set_error("bad image shape (%d,%d,%d)", H, W, C); return OBIA_E_INVALID; }
+    if ((long long)H * W > 0x7fffffffLL) { set_error("rasters above 2^31 pixels must go through the tiled driver"); return OBIA_E_INVALID; }
+    if (C > 16) { set_error("more than 16 bands not supported (got %d)", C); return OBIA_E_UNSUPPORTED; }
+    if (p->start_label != 0 && p->start_label != 1) { set_error("start_label should be 0 or 1."); return OBIA_E_INVALID; }
+    if (p->convert2lab == 1 && C != 3) { set_error("Lab colorspace conversion requires a RGB image."); return OBIA_E_INVALID; }
+    if (!(p->compactness > 0.0)) { set_error("compactness must be positive"); return OBIA_E_INVALID; }
+    if (p->n_segments <= 0) { set_error("n_segments must be positive"); return OBIA_E_INVALID; }
+    if (p->max_num_iter < 0) { set_error("max_num_iter must be >= 0"); return OBIA_E_INVALID; }
+    if (p->slic_zero) { set_error("slic_zero=True is not implemented in this version"); return OBIA_E_UNSUPPORTED; }
+    return OBIA_OK;
+}
+
+// Whole-raster SLIC up to the pre-connectivity labels (device pointers).  On return b holds the plan.
+int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                const obia_slic_params *p, SlicBatch &b) {
+    Arena &A = ctx->arena;
+    b.nprob = 1;
+    b.C = C;
+    b.CP = (C + 3) & ~3;
+    b.masked = mask != nullptr;
+    b.start_label = p->start_label;
+    b.max_iter = p->max_num_iter;
+    b.exit_on_fixed_point = p->exit_on_fixed_point != 0;
+    b.total_pix = (long long)H * W;
+    SlicProblem P{};
+    P.H = H; P.W = W; P.pix_off = 0;
+    b.probs.assign(1, P);
+    b.windows.assign(1, SrcWindow{0, 0, H, W, 0});
+    b.d_windows = A.get<SrcWindow>(1);
+    b.d_feat = A.get<float>((size_t)b.total_pix * b.CP);
+    b.d_labels = A.get<int32_t>((size_t)b.total_pix);
+    if (!b.d_windows || !b.d_feat || !b.d_labels) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemcpyAsync(b.d_windows, b.windows.data(), sizeof(SrcWindow), hipMemcpyHostToDevice, ctx->stream));
+    b.d_mask = const_cast<uint8_t *>(mask);
+    const int to_lab = (C == 3 && p->convert2lab != 0) ? 1 : 0;
+    const float ratio = (float)(1.0 / p->compactness);   // `image * ratio`: float32 array times Python float
+    OBIA_TRY(slic_prepare_features(ctx, b, img, H, W, p->normalize_bands, to_lab, ratio));
+    std::vector<int> nseg(1, p->n_segments);
+    OBIA_TRY(slic_plan_and_seed(ctx, b, nseg));
+    if (b.probs[0].K <= 0) {
+        set_error("mask is empty: nothing to segment");
+        return OBIA_E_EMPTY;
+    }
+    OBIA_TRY(slic_run_sweeps(ctx, b));
+    return OBIA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int obia_slic_assign_only_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                                  const obia_slic_params *params, int32_t *labels_pre_out, int *n_centroids_out) {
+    OBIA_TRY(check_ctx(ctx));
+    OBIA_TRY(check_slic_args(img, H, W, C, params));
+    if (!labels_pre_out) { set_error("null output"); return OBIA_E_INVALID; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    SlicBatch b;
+    int rc;
+    {
+        ScopedSpan total(ctx, T_TOTAL);
+        rc = slic_single(ctx, img, H, W, C, mask, params, b);
+        if (rc == OBIA_OK) {
+            hipError_t e = hipMemcpyAsync(labels_pre_out, b.d_labels, sizeof(int32_t) * (size_t)H * W, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(e)); rc = OBIA_E_HIP; }
+        }
+    }
+    if (rc != OBIA_OK) return rc;
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    if (n_centroids_out) *n_centroids_out = b.probs[0].K;
+    return OBIA_OK;
+}
+
+int obia_slic_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                      const obia_slic_params *params, int32_t *labels_out, int *n_labels_out) {
+    OBIA_TRY(check_ctx(ctx));
+    OBIA_TRY(check_slic_args(img, H, W, C, params));
+    if (!labels_out) { set_error("null output"); return OBIA_E_INVALID; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    SlicBatch b;
+    int n_labels = 0;
+    int rc;
+    {
+        ScopedSpan total(ctx, T_TOTAL);
+        rc = slic_single(ctx, img, H, W, C, mask, params, b);
+        if (rc == OBIA_OK) {
+            if (params->enforce_connectivity) {
+                // segment_size = mask.sum() / n_centroids  |  prod(shape) / n_centroids  (slic_superpixels.py:321-326)
+                const double segment_size = (double)b.probs[0].n_valid / (double)b.probs[0].K;
+                const int min_size = (int)(params->min_size_factor * segment_size);
+                const int max_size = (int)(params->max_size_factor * segment_size);
+                rc = enforce_connectivity_dev(ctx, b.d_labels, H, W, min_size, max_size, params->start_label, labels_out, &n_labels);
+            } else {
+                hipError_t e = hipMemcpyAsync(labels_out, b.d_labels, sizeof(int32_t) * (size_t)H * W, hipMemcpyDeviceToDevice, ctx->stream);
+                if (e != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(e)); rc = OBIA_E_HIP; }
+                n_labels = b.probs[0].K;
+            }
+        }
+    }
+    if (rc != OBIA_OK) return rc;
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    if (n_labels_out) *n_labels_out = n_labels;
+    return OBIA_OK;
+}
+
+int obia_slic_f32(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                  const obia_slic_params *params, int32_t *labels_out, int *n_labels_out) {
+    OBIA_TRY(check_ctx(ctx));
+    OBIA_TRY(check_slic_args(img, H, W, C, params));
+    if (!labels_out) { set_error("null output"); return OBIA_E_INVALID; }
+    const size_t npix = (size_t)H * W;
+    float *d_img = nullptr;
+    uint8_t *d_mask = nullptr;
+    int32_t *d_lab = nullptr;
+    int rc = OBIA_OK;
+    // caller-visible buffers are not part of the workspace arena: plain allocations for the call
+    if (hipMalloc(&d_img, npix * C * sizeof(float)) != hipSuccess || hipMalloc(&d_lab, npix * sizeof(int32_t)) != hipSuccess ||
+        (mask && hipMalloc(&d_mask, npix) != hipSuccess)) {
+        set_error("device allocation for host-pointer call failed");
+        rc = OBIA_E_NOMEM;
+    }
+    if (rc == OBIA_OK && hipMemcpyAsync(d_img, img, npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK && mask && hipMemcpyAsync(d_mask, mask, npix, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK) rc = obia_slic_f32_dev(ctx, d_img, H, W, C, d_mask, params, d_lab, n_labels_out);
+    if (rc == OBIA_OK && hipMemcpyAsync(labels_out, d_lab, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == OBIA_E_HIP) set_error("host<->device copy failed in obia_slic_f32");
+    (void)hipFree(d_img); (void)hipFree(d_lab); (void)hipFree(d_mask);
+    return rc;
+}
+
+int obia_enforce_connectivity_i32_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size, int max_size,
+                                      int start_label, int32_t *labels_out, int *n_labels_out) {
+    OBIA_TRY(check_ctx(ctx));
+    if (!labels_in || !labels_out || H <= 0 || W <= 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    if (start_label != 0 && start_label != 1) { set_error("start_label should be 0 or 1."); return OBIA_E_INVALID; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    int n = 0;
+    OBIA_TRY(enforce_connectivity_dev(ctx, labels_in, H, W, min_size, max_size, start_label, labels_out, &n));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    if (n_labels_out) *n_labels_out = n;
+    return OBIA_OK;
+}
+
+int obia_zonal_stats_f32_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                             const int32_t *bands, int n_bands, int n_labels, int start_label, int64_t *count_out,
+                             double *mean_out, double *var_out, float *min_out, float *max_out) {
+    OBIA_TRY(check_ctx(ctx));
+    if (!raw || !labels || !count_out || !mean_out || !var_out || !min_out || !max_out) { set_error("null pointer argument"); return OBIA_E_INVALID; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    OBIA_TRY(zonal_stats_dev(ctx, raw, labels, H, W, C, bands, n_bands, n_labels, start_label, count_out, mean_out, var_out, min_out, max_out));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    return OBIA_OK;
+}
+
+int obia_zonal_stats_f32(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                         const int32_t *bands, int n_bands, int n_labels, int start_label, int64_t *count_out,
+                         double *mean_out, double *var_out, float *min_out, float *max_out) {
+    OBIA_TRY(check_ctx(ctx));
+    if (!raw || !labels || H <= 0 || W <= 0 || C <= 0 || n_labels < 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    const size_t npix = (size_t)H * W;
+    const int nb = bands ? n_bands : C;
+    if (nb < 1 || nb > 16) { set_error("n_bands %d out of range (1..16)", nb); return OBIA_E_UNSUPPORTED; }
+    const size_t nl = (size_t)(n_labels > 0 ? n_labels : 1), nlb = nl * nb;
+    float *d_raw = nullptr; int32_t *d_lab = nullptr;
+    char *d_out = nullptr;
+    const size_t out_bytes = nl * 8 + nlb * (8 + 8 + 4 + 4);
+    int rc = OBIA_OK;
+    if (hipMalloc(&d_raw, npix * C * sizeof(float)) != hipSuccess || hipMalloc(&d_lab, npix * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&d_out, out_bytes) != hipSuccess) {
+        set_error("device allocation for host-pointer call failed");
+        rc = OBIA_E_NOMEM;
+    }
+    int64_t *d_cnt = (int64_t *)d_out;
+    double *d_mean = (double *)(d_out + nl * 8), *d_var = d_mean + nlb;
+    float *d_mn = (float *)(d_var + nlb), *d_mx = d_mn + nlb;
+    if (rc == OBIA_OK && hipMemcpyAsync(d_raw, raw, npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK && hipMemcpyAsync(d_lab, labels, npix * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK) rc = obia_zonal_stats_f32_dev(ctx, d_raw, d_lab, H, W, C, bands, n_bands, n_labels, start_label, d_cnt, d_mean, d_var, d_mn, d_mx);
+    if (rc == OBIA_OK && n_labels > 0) {
+        bool ok = hipMemcpyAsync(count_out, d_cnt, nl * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(mean_out, d_mean, nlb * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(var_out, d_var, nlb * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(min_out, d_mn, nlb * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(max_out, d_mx, nlb * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        if (!ok) rc = OBIA_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == OBIA_E_HIP) set_error("host<->device copy failed in obia_zonal_stats_f32");
+    (void)hipFree(d_raw); (void)hipFree(d_lab); (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

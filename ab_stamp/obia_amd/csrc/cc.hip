@@ -1,0 +1,457 @@
+// cc.hip -- connectivity enforcement of a SLIC label map on gfx950.
+//
+// Restates _enforce_label_connectivity_cython (scikit-image _slic.pyx, called from
+// slic_superpixels.py:320-328; oracle/obia_oracle.c: obia_oracle_enforce_connectivity).  The reference
+// is a raster-order sequential BFS.  What is order-INDEPENDENT in it is reproduced exactly:
+//   * components are the 4-connected regions of equal label (masked pixels excluded);
+//   * a component keeps its own label iff size >= min_size, and surviving components are numbered
+//     consecutively from start_label in raster order of their FIRST pixel
+//     (union-find by minimum pixel index -> the root IS the first pixel; ranks by a prefix sum);
+//   * a component smaller than min_size takes the label of `adjacent`: the LAST neighbour pixel, in
+//     the BFS order of the reference (neighbour order x+1, x-1, y+1, y-1), that already carries a
+//     label -- i.e. belongs to a component whose first pixel precedes this BFS's start pixel.  Small
+//     components are rare and small, so one lane replays the BFS of each of them exactly; chains
+//     small -> small -> ... -> survivor are resolved afterwards.
+// Deliberately NOT reproduced (DESIGN.md "connectivity"): the split of components that reach max_size
+// (the BFS of the reference stops there and the rest is re-seeded, an order-dependent cut that no
+// BASELINE configuration triggers), and the exact bookkeeping of small components that find no
+// labelled neighbour on their first BFS and are re-seeded from a later pixel (replayed here with the
+// same start pixels, but neighbours are classified by root order only).
+#include "slic.hpp"
+
+namespace obia {
+
+// dense pixel index -> problem (binary search on pix_off; used on roots / small components only)
+__device__ __forceinline__ int find_prob(const CcProblem *__restrict__ probs, int nprob, long long g) {
+    int lo = 0, hi = nprob - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (probs[mid].pix_off <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int ld_agent(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int find_root(const int *parent, int i) {
+    int p;
+    while ((p = ld_agent(&parent[i])) != i) i = p;
+    return i;
+}
+
+// link the larger root under the smaller one; lock-free (Komura / Playne-Hawick style)
+__device__ __forceinline__ void unite(int *parent, int a, int b) {
+    for (;;) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+// ---- tile-local union-find in LDS -------------------------------------------------------------------------------
+// A workgroup resolves the components of one 64x32 pixel tile entirely in LDS (labels + 16-bit local parents),
+// then publishes parent[pixel] = GLOBAL index of the pixel's tile-local root.  Local indices are row-major inside
+// the tile, so "smaller local index" == "smaller global index": the local root is the first pixel of the tile's
+// part of the component, and linking larger roots under smaller ones across tiles (cc_seam_kernel) keeps the
+// global invariant root == first pixel in raster order.
+constexpr int CT_W = 64, CT_H = 32, CT_N = CT_W * CT_H;
+
+__device__ __forceinline__ int lfind(const unsigned short *par, int i) {
+    int p;
+    while ((p = par[i]) != i) i = p;
+    return i;
+}
+// 16-bit atomicMin on LDS (CAS on the enclosing 32-bit word); returns the previous value of par[i]
+__device__ __forceinline__ int latomic_min16(unsigned short *par, int i, int v) {
+    unsigned *wptr = reinterpret_cast<unsigned *>(par) + (i >> 1);
+    const int sh = (i & 1) * 16;
+    unsigned seen = *wptr;
+    for (;;) {
+        const int cur = (int)((seen >> sh) & 0xffffu);
+        if (cur <= v) return cur;
+        const unsigned prev = atomicCAS(wptr, seen, (seen & ~(0xffffu << sh)) | ((unsigned)v << sh));
+        if (prev == seen) return cur;
+        seen = prev;
+    }
+}
+__device__ __forceinline__ void lunite(unsigned short *par, int a, int b) {
+    for (;;) {
+        a = lfind(par, a);
+        b = lfind(par, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        const int old = latomic_min16(par, b, a);
+        if (old == b) return;   // b was a root and now hangs under a
+        b = old;                // b had been linked elsewhere meanwhile: unite a with where it points
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
+                                                      int *__restrict__ parent, int *__restrict__ size, int mask_label) {
+    __shared__ int s_lab[CT_N];
+    __shared__ unsigned short s_par[CT_N];
+    const CcProblem P = probs[blockIdx.y];
+    const int tiles_x = (P.W + CT_W - 1) / CT_W;
+    const int tile = blockIdx.x;
+    if (tile >= tiles_x * ((P.H + CT_H - 1) / CT_H)) return;
+    const int ty0 = (tile / tiles_x) * CT_H, tx0 = (tile % tiles_x) * CT_W;
+    const int tid = threadIdx.x;
+    // 1. labels -> LDS; parents start at the head of the horizontal run where that is one step away
+    for (int i = tid; i < CT_N; i += 256) {
+        const int ly = i / CT_W, lx = i % CT_W;
+        const int y = ty0 + ly, x = tx0 + lx;
+        s_lab[i] = (y < P.H && x < P.W) ? lab[P.pix_off + (long long)y * P.W + x] : mask_label;
+    }
+    __syncthreads();
+    for (int i = tid; i < CT_N; i += 256) {
+        const int lx = i % CT_W;
+        const int l = s_lab[i];
+        s_par[i] = (unsigned short)((l != mask_label && lx > 0 && s_lab[i - 1] == l) ? i - 1 : i);
+    }
+    __syncthreads();
+    // 2. vertical contacts (only the first pixel of a horizontal contact issues the union)
+    for (int i = tid + CT_W; i < CT_N; i += 256) {
+        const int lx = i % CT_W;
+        const int l = s_lab[i];
+        if (l == mask_label || s_lab[i - CT_W] != l) continue;
+        const bool left_same = lx > 0 && s_lab[i - 1] == l && s_lab[i - CT_W - 1] == l;
+        if (!left_same) lunite(s_par, i, i - CT_W);
+    }
+    __syncthreads();
+    // 3. publish: global index of the local root
+    for (int i = tid; i < CT_N; i += 256) {
+        const int ly = i / CT_W, lx = i % CT_W;
+        const int y = ty0 + ly, x = tx0 + lx;
+        if (y >= P.H || x >= P.W) continue;
+        const long long g = P.pix_off + (long long)y * P.W + x;
+        int p = -1;
+        if (s_lab[i] != mask_label) {
+            const int r = lfind(s_par, i);
+            p = (int)(P.pix_off + (long long)(ty0 + r / CT_W) * P.W + tx0 + r % CT_W);
+        }
+        parent[g] = p;
+        size[g] = 0;
+    }
+}
+
+// contacts across tile borders: the pixels of the first row / first column of every tile against their upper / left
+// neighbour (a few percent of the pixels), on the global parents
+__global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
+                                                      int *__restrict__ parent, int mask_label) {
+    const CcProblem P = probs[blockIdx.y];
+    const int W = P.W;
+    const int n_hrows = (P.H - 1) / CT_H;          // horizontal seams: rows CT_H, 2*CT_H, ...
+    const int n_vcols = (W - 1) / CT_W;            // vertical seams: columns CT_W, 2*CT_W, ...
+    const long long n_h = (long long)n_hrows * W, n_v = (long long)n_vcols * P.H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_h + n_v; i += (long long)gridDim.x * blockDim.x) {
+        int y, x, dy, dx;
+        if (i < n_h) { y = (int)(i / W + 1) * CT_H; x = (int)(i % W); dy = 1; dx = 0; }
+        else { const long long j = i - n_h; x = (int)(j / P.H + 1) * CT_W; y = (int)(j % P.H); dy = 0; dx = 1; }
+        const long long g = P.pix_off + (long long)y * W + x;
+        const int l = lab[g];
+        if (l == mask_label) continue;
+        const long long gn = g - (long long)dy * W - dx;
+        if (lab[gn] == l) unite(parent, (int)g, (int)gn);
+    }
+}
+
+// flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n) {
+    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < n; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+        int r = -1;
+        if (i < n && parent[i] >= 0) r = find_root(parent, (int)i);
+        bool todo = r >= 0;
+        while (true) {
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const int rr = __shfl(r, leader);
+            const unsigned long long same = __ballot(todo && r == rr);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[rr], (int)__popcll(same));
+            if (r == rr) todo = false;
+        }
+        if (i < n && r >= 0) parent[i] = r;   // roots only move to smaller indices, final value is the root
+    }
+}
+
+constexpr int SCAN_NT = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_NT * SCAN_PER;
+
+__global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                                   const int *__restrict__ parent, const int *__restrict__ size,
+                                                                   long long n, int *__restrict__ block_sums,
+                                                                   int *__restrict__ counters /*[0]=n_small [1]=small_px*/) {
+    __shared__ int s_w[SCAN_NT / 64];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    int c = 0, nsmall = 0, spx = 0;
+    for (int j = 0; j < SCAN_PER; ++j) {
+        const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
+        if (i < n && parent[i] == (int)i) {
+            const int sz = size[i];
+            const int min_size = probs[find_prob(probs, nprob, i)].min_size;
+            if (sz >= min_size) c += 1;
+            else { nsmall += 1; spx += sz; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); nsmall += __shfl_xor(nsmall, off); spx += __shfl_xor(spx, off); }
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = c;
+        if (nsmall) { atomicAdd(&counters[0], nsmall); atomicAdd(&counters[1], spx); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of block_sums in place, single workgroup; total -> counters[2]
+__global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ block_sums, int nb, int *__restrict__ counters) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, nb);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_sums[i];
+    s_part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - s;
+    for (int i = lo; i < hi; ++i) { const int v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (tid == 1023) counters[2] = s_part[1023];
+}
+
+// newlab[root] = rank (>= 0) for survivors, -(index+2) for small components (collected in small_list)
+__global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                                const int *__restrict__ parent, const int *__restrict__ size,
+                                                                long long n, const int *__restrict__ block_sums,
+                                                                int *__restrict__ newlab, int *__restrict__ small_list,
+                                                                int *__restrict__ small_qoff, int *__restrict__ counters /*[3]=list cursor [4]=queue cursor*/) {
+    __shared__ int s_w[SCAN_NT / 64];
+    __shared__ int s_run;
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = block_sums[blockIdx.x];
+    __syncthreads();
+    for (int j = 0; j < SCAN_PER; ++j) {
+        const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
+        int flag = 0;
+        bool small = false;
+        int sz = 0;
+        if (i < n && parent[i] == (int)i) {
+            sz = size[i];
+            flag = sz >= probs[find_prob(probs, nprob, i)].min_size;
+            small = !flag;
+        }
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) s_w[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += s_w[w];
+        const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (flag) newlab[i] = s_run + before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (small) {
+            const int idx = atomicAdd(&counters[3], 1);
+            small_list[idx] = (int)i;
+            small_qoff[idx] = atomicAdd(&counters[4], sz);
+            newlab[i] = -(idx + 2);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += total;
+        __syncthreads();
+    }
+}
+
+// BFS of the reference over the component rooted at r, started at `start`; neighbour order
+// (x+1, x-1, y+1, y-1).  A neighbour pixel of another component counts as "already labelled" when that
+// component was labelled before this BFS started: a surviving component as soon as the scan reached its
+// first pixel (root < start); a small component once one of its own BFS attempts found a labelled
+// neighbour (settle < start; a small component that finds none is written back as 0 == unset when
+// start_label is 1).  Returns the last labelled neighbour met.
+__device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict__ newlab,
+                          const int *__restrict__ settle, int r, int start, int mark, int H, int W, int base,
+                          int *__restrict__ q, int32_t *__restrict__ out, int *n_out) {
+    int head = 0, tail = 1, adjacent = -1;
+    q[0] = start;
+    out[start] = mark;
+    while (head < tail) {
+        const int p = q[head++];
+        const int y = (p - base) / W, x = (p - base) - y * W;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
+            const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const int nb = base + yy * W + xx;
+            const int rn = parent[nb];
+            if (rn == r) {
+                if (out[nb] != mark) { out[nb] = mark; q[tail++] = nb; }
+            } else if (rn >= 0) {
+                const int nl = newlab[rn];
+                const int since = (nl >= 0) ? rn : settle[-nl - 2];
+                if (since < start) adjacent = nb;     // the LAST labelled neighbour met wins
+            }
+        }
+    }
+    *n_out = tail;
+    return adjacent;
+}
+
+// One lane replays the reference's treatment of one small component: BFS from its first pixel; if no
+// labelled neighbour is found and start_label is 1 the component is written back as 0 (== unset), the
+// raster scan meets it again at its next pixel and the BFS is replayed from there.  settle_out[s] = start
+// pixel of the attempt that found a neighbour (INT_MAX if none), target[s] = that neighbour pixel.
+// `out` doubles as the visited map (rewritten by the final relabel pass).  Rounds are Jacobi iterations
+// on `settle` (small components adjacent to other small components); *changed reports progress.
+__global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                          const int *__restrict__ parent, const int *__restrict__ newlab,
+                                                          const int *__restrict__ small_list, const int *__restrict__ small_qoff,
+                                                          int n_small, int start_label,
+                                                          const int *__restrict__ settle_in, int *__restrict__ settle_out,
+                                                          int *__restrict__ queue, int32_t *__restrict__ out,
+                                                          int *__restrict__ target, int *__restrict__ changed) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_small) return;
+    const int r = small_list[s];
+    const CcProblem P = probs[find_prob(probs, nprob, r)];
+    const int H = P.H, W = P.W, base = (int)P.pix_off;
+    int *q = queue + small_qoff[s];
+    int csize = 0;
+    int start = r;
+    int adjacent = replay_bfs(parent, newlab, settle_in, r, r, -(s + 2), H, W, base, q, out, &csize);
+    if (adjacent < 0 && start_label == 1) {
+        start = 0x7fffffff;
+        for (int a = 1; a < csize && adjacent < 0; ++a) {
+            for (int i = 1; i < csize; ++i) {   // insertion sort: raster order of the component's pixels
+                const int v = q[i];
+                int j = i - 1;
+                while (j >= 0 && q[j] > v) { q[j + 1] = q[j]; --j; }
+                q[j + 1] = v;
+            }
+            const int st = q[a];
+            for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the last attempt
+            int n2 = 0;
+            adjacent = replay_bfs(parent, newlab, settle_in, r, st, -(s + 2), H, W, base, q, out, &n2);
+            if (adjacent >= 0) start = st;
+        }
+    }
+    for (int i = 0; i < csize; ++i) out[q[i]] = 0;
+    target[s] = adjacent;
+    settle_out[s] = start;
+    if (settle_in[s] != start) atomicOr(changed, 1);
+}
+
+__global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_small, int *__restrict__ settle) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_small) settle[s] = small_list[s];
+}
+
+// final labels: survivors get rank + start_label; small components follow their adjacency chain
+__global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__ parent, const int *__restrict__ newlab,
+                                                         const int *__restrict__ target, long long n, int start_label,
+                                                         int mask_label, int32_t *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = parent[i];
+        int res;
+        if (r < 0) res = mask_label;
+        else {
+            int nl = newlab[r];
+            int hops = 0;
+            while (nl < 0) {
+                const int t = target[-nl - 2];
+                if (t < 0 || ++hops > 64) { nl = -1; break; }
+                nl = newlab[parent[t]];
+            }
+            res = (nl >= 0) ? nl + start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
+        }
+        out[i] = res;
+    }
+}
+
+int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
+                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out) {
+    ScopedSpan span(ctx, T_CC);
+    Arena &A = ctx->arena;
+    const long long n = total_pix;
+    const int np = (int)probs.size();
+    if (np <= 0 || n <= 0 || n > 0x7fffffffLL) { set_error("label batch of %lld pixels not supported", n); return OBIA_E_INVALID; }
+    const int mask_label = start_label - 1;
+    CcProblem *d_probs = A.get<CcProblem>(np);
+    int *parent = A.get<int>(n), *size = A.get<int>(n), *newlab = A.get<int>(n);
+    const int nb = cdiv(n, SCAN_CHUNK);
+    int *block_sums = A.get<int>(nb);
+    int *counters = A.get<int>(8);
+    if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemcpyAsync(d_probs, probs.data(), sizeof(CcProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+    int gs = cdiv(n, 256 * 4);
+    if (gs > 65535 * 4) gs = 65535 * 4;
+    {
+        int max_tiles = 1;
+        long long max_seam = 1;
+        for (auto &P : probs) {
+            const int t = cdiv(P.W, CT_W) * cdiv(P.H, CT_H);
+            if (t > max_tiles) max_tiles = t;
+            const long long sm = (long long)((P.H - 1) / CT_H) * P.W + (long long)((P.W - 1) / CT_W) * P.H;
+            if (sm > max_seam) max_seam = sm;
+        }
+        hipLaunchKernelGGL(cc_tile_kernel, dim3(max_tiles, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label);
+        int sg = cdiv(max_seam, 256);
+        if (sg > 65535) sg = 65535;
+        hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
+    }
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n);
+    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters);
+    hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
+    int hc[8];
+    OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));   // also orders the pageable `probs` upload
+    const int n_small = hc[0], small_px = hc[1], n_surv = hc[2];
+    int *small_list = A.get<int>(n_small > 0 ? n_small : 1);
+    int *small_qoff = A.get<int>(n_small > 0 ? n_small : 1);
+    int *target = A.get<int>(n_small > 0 ? n_small : 1);
+    int *queue = A.get<int>(small_px > 0 ? small_px : 1);
+    if (!small_list || !small_qoff || !target || !queue) return OBIA_E_NOMEM;
+    hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
+                       newlab, small_list, small_qoff, counters);
+    if (n_small > 0) {
+        int *settle_a = A.get<int>(n_small), *settle_b = A.get<int>(n_small);
+        if (!settle_a || !settle_b) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
+        hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle_a);
+        // optimistic start (every small component labelled at its first pixel), then Jacobi rounds until the
+        // settle times stop moving; one round settles everything unless small components that find no
+        // labelled neighbour touch each other
+        for (int round = 0; round < 32; ++round) {
+            OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
+                               small_list, small_qoff, n_small, start_label, settle_a, settle_b, queue, labels_out, target,
+                               counters + 5);
+            int changed = 0;
+            OBIA_TRY(read_back(ctx, &changed, counters + 5, sizeof(int)));
+            std::swap(settle_a, settle_b);
+            if (!changed) break;
+        }
+    }
+    hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
+                       mask_label, labels_out);
+    OBIA_HIP_TRY(hipGetLastError());
+    if (h_n_labels_out) *h_n_labels_out = n_surv;
+    return OBIA_OK;
+}
+
+int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size, int max_size,
+                             int start_label, int32_t *labels_out, int *h_n_labels_out) {
+    (void)max_size;   // components are never split at max_size (see the header of this file)
+    std::vector<CcProblem> probs(1, CcProblem{H, W, 0, min_size, 0});
+    return enforce_connectivity_batch(ctx, probs, labels_in, (long long)H * W, start_label, labels_out, h_n_labels_out);
+}
+
+}  // namespace obia

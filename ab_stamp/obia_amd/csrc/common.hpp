@@ -1,0 +1,97 @@
+// common.hpp -- context, device workspace arena, error plumbing shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/obia_hip.h"
+
+namespace obia {
+
+void set_error(const char *fmt, ...);
+
+#define OBIA_HIP_TRY(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            obia::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return OBIA_E_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+#define OBIA_TRY(expr)            \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != OBIA_OK) return rc__; \
+    } while (0)
+
+// Bump allocator over a few large hipMalloc blocks.  reset() keeps the memory; when a call needed
+// more than one block the blocks are merged into one at the next reset, so a steady-state call
+// performs no hipMalloc at all.
+class Arena {
+  public:
+    ~Arena() { release(); }
+    void *alloc(size_t bytes);
+    template <typename T> T *get(size_t n) { return static_cast<T *>(alloc(n * sizeof(T))); }
+    void reset();
+    void release();
+    // mark()/rewind(): scoped reuse inside one call (per tile batch)
+    struct Mark { size_t block, used, total; };
+    Mark mark() const;
+    void rewind(const Mark &m);
+    size_t capacity() const;
+    bool failed() const { return failed_; }
+
+  private:
+    struct Block { char *p; size_t size; size_t used; };
+    std::vector<Block> blocks_;
+    size_t high_water_ = 0, cur_total_ = 0, cur_ = 0;
+    bool failed_ = false;
+};
+
+struct Timing {
+    double assign_ms = 0, prepass_ms = 0, feat_ms = 0, cc_ms = 0, zonal_ms = 0, total_ms = 0;
+    double assign_px = 0, prepass_px = 0;   // pixels processed by the timed colour / pre-pass sweeps (sum over launches)
+    int sweeps = 0;
+};
+
+}  // namespace obia
+
+struct obia_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    obia::Arena arena;
+    void *pinned = nullptr;          // small pinned host staging buffer for scalar read-backs
+    size_t pinned_bytes = 0;
+    bool profiling = false;
+    obia::Timing timing;
+    // event pairs recorded around kernels of interest; resolved (one sync) at the end of the call
+    struct Span { int kind; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+};
+
+namespace obia {
+
+enum TimeKind { T_ASSIGN = 0, T_FEAT = 2, T_CC = 3, T_ZONAL = 4, T_TOTAL = 5, T_PREPASS = 6 };
+
+// Records a HIP event pair around a region of the context's stream when profiling is on; no host
+// synchronisation happens until resolve_timing().
+struct ScopedSpan {
+    obia_ctx *ctx; bool on; size_t idx;
+    ScopedSpan(obia_ctx *c, int kind);
+    ~ScopedSpan();
+};
+void begin_timing(obia_ctx *ctx);
+void resolve_timing(obia_ctx *ctx);
+
+int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  // async copy + stream sync
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace obia

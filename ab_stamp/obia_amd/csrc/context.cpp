@@ -1,0 +1,253 @@
+// context.cpp -- context lifetime, workspace arena, error string, timing spans.
+#include "common.hpp"
+
+#include <cstdarg>
+
+namespace obia {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+void *Arena::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    for (; cur_ < blocks_.size(); ++cur_) {
+        Block &b = blocks_[cur_];
+        if (b.size - b.used >= bytes) {
+            void *p = b.p + b.used;
+            b.used += bytes;
+            cur_total_ += bytes;
+            if (cur_total_ > high_water_) high_water_ = cur_total_;
+            return p;
+        }
+    }
+    size_t want = bytes;
+    size_t grow = blocks_.empty() ? (size_t(64) << 20) : 2 * blocks_.back().size;
+    if (grow > (size_t(4) << 30)) grow = size_t(4) << 30;
+    if (want < grow) want = grow;
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        if (want == bytes || hipMalloc(&p, bytes) != hipSuccess) {
+            failed_ = true;
+            set_error("workspace hipMalloc of %zu bytes failed", bytes);
+            return nullptr;
+        }
+        want = bytes;
+    }
+    blocks_.push_back(Block{static_cast<char *>(p), want, bytes});
+    cur_ = blocks_.size() - 1;
+    cur_total_ += bytes;
+    if (cur_total_ > high_water_) high_water_ = cur_total_;
+    return p;
+}
+
+Arena::Mark Arena::mark() const {
+    Mark m;
+    m.block = cur_ < blocks_.size() ? cur_ : blocks_.size();
+    m.used = m.block < blocks_.size() ? blocks_[m.block].used : 0;
+    m.total = cur_total_;
+    return m;
+}
+
+void Arena::rewind(const Mark &m) {
+    for (size_t i = m.block + 1; i < blocks_.size(); ++i) blocks_[i].used = 0;
+    if (m.block < blocks_.size()) blocks_[m.block].used = m.used;
+    cur_ = m.block;
+    cur_total_ = m.total;
+}
+
+void Arena::reset() {
+    failed_ = false;
+    cur_total_ = 0;
+    cur_ = 0;
+    if (blocks_.size() > 1) {
+        // merge: one block large enough for the high-water mark of the previous calls
+        size_t total = 0;
+        for (auto &b : blocks_) total += b.size;
+        for (auto &b : blocks_) (void)hipFree(b.p);
+        blocks_.clear();
+        void *p = nullptr;
+        if (hipMalloc(&p, high_water_ + (high_water_ >> 3)) == hipSuccess) blocks_.push_back(Block{static_cast<char *>(p), high_water_ + (high_water_ >> 3), 0});
+        (void)total;
+    } else if (!blocks_.empty()) {
+        blocks_[0].used = 0;
+    }
+}
+
+void Arena::release() {
+    for (auto &b : blocks_) (void)hipFree(b.p);
+    blocks_.clear();
+}
+
+size_t Arena::capacity() const {
+    size_t t = 0;
+    for (auto &b : blocks_) t += b.size;
+    return t;
+}
+
+static hipEvent_t get_event(obia_ctx *ctx) {
+    if (ctx->events_used == ctx->event_pool.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        ctx->event_pool.push_back(e);
+    }
+    return ctx->event_pool[ctx->events_used++];
+}
+
+ScopedSpan::ScopedSpan(obia_ctx *c, int kind) : ctx(c), on(c->profiling), idx(0) {
+    if (!on) return;
+    obia_ctx::Span s{kind, get_event(ctx), get_event(ctx)};
+    (void)hipEventRecord(s.a, ctx->stream);
+    idx = ctx->spans.size();
+    ctx->spans.push_back(s);
+}
+ScopedSpan::~ScopedSpan() {
+    if (on) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+}
+
+void begin_timing(obia_ctx *ctx) {
+    ctx->spans.clear();
+    ctx->events_used = 0;
+    ctx->timing = Timing();
+}
+
+void resolve_timing(obia_ctx *ctx) {
+    if (!ctx->profiling) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->spans) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, s.a, s.b);
+        switch (s.kind) {
+            case T_ASSIGN: ctx->timing.assign_ms += ms; ctx->timing.sweeps += 1; break;
+            case T_FEAT: ctx->timing.feat_ms += ms; break;
+            case T_CC: ctx->timing.cc_ms += ms; break;
+            case T_ZONAL: ctx->timing.zonal_ms += ms; break;
+            case T_TOTAL: ctx->timing.total_ms += ms; break;
+            case T_PREPASS: ctx->timing.prepass_ms += ms; break;
+            default: break;
+        }
+    }
+    ctx->spans.clear();
+}
+
+int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes > ctx->pinned_bytes) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        OBIA_HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    OBIA_HIP_TRY(hipMemcpyAsync(ctx->pinned, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(host_dst, ctx->pinned, bytes);
+    return OBIA_OK;
+}
+
+}  // namespace obia
+
+using namespace obia;
+
+extern "C" {
+
+int obia_abi_version(void) { return OBIA_ABI_VERSION; }
+
+const char *obia_last_error(void) { return g_last_error.c_str(); }
+
+static obia_ctx *create_impl(int device_id, void *stream, bool own) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available");
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) {
+        set_error("device_id %d out of range (%d devices)", device_id, n);
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", device_id);
+        return nullptr;
+    }
+    obia_ctx *ctx = new obia_ctx();
+    ctx->device = device_id;
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            set_error("hipStreamCreate failed");
+            delete ctx;
+            return nullptr;
+        }
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    }
+    return ctx;
+}
+
+obia_ctx *obia_create(int device_id) { return create_impl(device_id, nullptr, true); }
+obia_ctx *obia_create_on_stream(int device_id, void *hip_stream) { return create_impl(device_id, hip_stream, false); }
+
+void obia_destroy(obia_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->arena.release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int obia_synchronize(obia_ctx *ctx) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return OBIA_OK;
+}
+
+int64_t obia_workspace_bytes(obia_ctx *ctx) { return ctx ? (int64_t)ctx->arena.capacity() : 0; }
+
+void obia_slic_default_params(obia_slic_params *p) {
+    if (!p) return;
+    p->n_segments = 100;
+    p->compactness = 10.0;
+    p->max_num_iter = 10;
+    p->convert2lab = -1;
+    p->enforce_connectivity = 1;
+    p->min_size_factor = 0.5;
+    p->max_size_factor = 3.0;
+    p->slic_zero = 0;
+    p->start_label = 1;
+    p->normalize_bands = 0;
+    p->exit_on_fixed_point = 0;
+}
+
+int obia_set_profiling(obia_ctx *ctx, int enabled) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    ctx->profiling = enabled != 0;
+    return OBIA_OK;
+}
+
+double obia_last_timing(obia_ctx *ctx, int what) {
+    if (!ctx) return -1.0;
+    switch (what) {
+        case 0: return ctx->timing.assign_ms;
+        case 1: return (double)ctx->timing.sweeps;
+        case 2: return ctx->timing.feat_ms;
+        case 3: return ctx->timing.cc_ms;
+        case 4: return ctx->timing.zonal_ms;
+        case 5: return ctx->timing.total_ms;
+        case 6: return ctx->timing.prepass_ms;
+        case 7: return ctx->timing.assign_px;
+        case 8: return ctx->timing.prepass_px;
+        default: return -1.0;
+    }
+}
+
+}  // extern "C"

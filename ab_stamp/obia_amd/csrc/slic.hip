@@ -1,0 +1,555 @@
+// slic.hip -- batched SLIC engine for gfx950: feature preparation, seeding, centroid binning and the
+// pixel-centric assign + fused-accumulate sweep.
+//
+// What it restates (all third-party arithmetic reached from obia/segmentation/segment_boundaries.py:48-51):
+//   normalize_band                     segment_boundaries.py:11-16,32-33
+//   slic() driver                      skimage slic_superpixels.py:107-333
+//   _slic_cython assign/update loop    skimage _slic.pyx (0.18.3), see oracle/obia_oracle.c
+// The reference loop is segment-centric (each centroid scatters into its (4S+1)^2 window, ties to the
+// lowest k).  Here it is pixel-centric: centroids are binned by their CURRENT position every sweep, a
+// workgroup owning a 32x32 pixel tile stages into LDS exactly the centroids whose window intersects
+// the tile, and every lane takes the lexicographic minimum of (distance, k) over the candidates whose
+// window contains its pixel -- the same candidate set and the same tie rule.  Distances use the
+// reference's operation order in float32 with contraction off, so they are bit-equal to the x86
+// build.  The centroid update is fused into the sweep: per-lane run sums -> LDS partials -> one
+// global integer atomic per (tile, centroid, field); colour sums are 64-bit fixed point, so the sums
+// (and therefore the whole segmentation) do not depend on the order of the atomics.
+#include "slic.hpp"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace obia {
+
+// ------------------------------------------------------------------------------------------------
+// host: regular_grid((1,H,W), n)  -- skimage/util/_regular_grid.py:61-83
+// ------------------------------------------------------------------------------------------------
+void regular_grid_hw(long long H, long long W, long long n, long long out[4]) {
+    long long dims[3] = {1, H, W};
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (dims[order[j]] < dims[order[i]]) std::swap(order[i], order[j]);
+    double sd[3];
+    for (int i = 0; i < 3; ++i) sd[i] = (double)dims[order[i]];
+    double space = sd[0] * sd[1] * sd[2];
+    if (space <= (double)n) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    double st[3];
+    for (int i = 0; i < 3; ++i) st[i] = std::pow(space / (double)n, 1.0 / 3.0);
+    auto all_ge = [&]() { return sd[0] >= st[0] && sd[1] >= st[1] && sd[2] >= st[2]; };
+    if (!all_ge()) {
+        for (int d = 0; d < 3; ++d) {
+            st[d] = sd[d];
+            double sp = 1.0;
+            for (int e = d + 1; e < 3; ++e) sp *= sd[e];
+            if (d < 2) {
+                double v = std::pow(sp / (double)n, 1.0 / (double)(3 - d - 1));
+                for (int e = d + 1; e < 3; ++e) st[e] = v;
+            }
+            if (all_ge()) break;
+        }
+    }
+    long long start[3], step[3], s_of[3], t_of[3];
+    for (int i = 0; i < 3; ++i) {
+        start[i] = (long long)std::floor(st[i] / 2.0);
+        step[i] = (long long)std::nearbyint(st[i]);   // np.round: half to even
+    }
+    for (int i = 0; i < 3; ++i) { s_of[order[i]] = start[i]; t_of[order[i]] = step[i]; }
+    out[0] = s_of[1]; out[1] = t_of[1]; out[2] = s_of[2]; out[3] = t_of[2];
+}
+
+static long long slice_len(long long L, long long start, long long step) {
+    if (step == 0) return L;
+    if (start >= L) return 0;
+    return (L - start + step - 1) / step;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2key(float f) {   // order-preserving float -> uint
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+constexpr int FP_NT = 256;
+
+// K0a: per-band min/max of each problem window.  A row of a band-interleaved window is a flat run of
+// w*C floats; lanes read it as coalesced float4 (C % 4 == 0) or dwords, and the thread count in use is a
+// multiple of the band period so that every thread owns a fixed band (group).  grid = (blocks, nprob).
+template <int VEC>
+__global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restrict__ src, int Ws, int C,
+                                                            const SrcWindow *__restrict__ wins,
+                                                            unsigned *__restrict__ keys /*[nprob][C][2]*/,
+                                                            int *__restrict__ nonfinite) {
+    __shared__ unsigned s_mn[32], s_mx[32];
+    const int p = blockIdx.y;
+    const SrcWindow wdw = wins[p];
+    const int period = C / VEC;                 // threads per pixel
+    const int active = (FP_NT / period) * period;
+    const int tid = threadIdx.x;
+    if (tid < 32) { s_mn[tid] = 0xffffffffu; s_mx[tid] = 0u; }
+    __syncthreads();
+    float lo[VEC], hi[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { lo[v] = INFINITY; hi[v] = -INFINITY; }
+    bool bad = false;
+    if (tid < active) {
+        const long long row_vecs = (long long)wdw.w * period;
+        for (int y = blockIdx.x; y < wdw.h; y += gridDim.x) {
+            const float *row = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0) * C;
+            for (long long e = tid; e < row_vecs; e += active) {
+                float v[VEC];
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(row + 4 * e);
+                    v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+                } else v[0] = row[e];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    bad |= !(fabsf(v[q]) <= 3.4028234e38f);
+                    lo[q] = fminf(lo[q], v[q]);
+                    hi[q] = fmaxf(hi[q], v[q]);
+                }
+            }
+        }
+        const int band0 = (tid % period) * VEC;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+            if (lo[q] <= hi[q]) {
+                atomicMin(&s_mn[band0 + q], f2key(lo[q]));
+                atomicMax(&s_mx[band0 + q], f2key(hi[q]));
+            }
+        if (bad) atomicOr(&nonfinite[p], 1);
+    }
+    __syncthreads();
+    if (tid < C) {
+        if (s_mn[tid] != 0xffffffffu) atomicMin(&keys[((long long)p * C + tid) * 2 + 0], s_mn[tid]);
+        if (s_mx[tid] != 0u) atomicMax(&keys[((long long)p * C + tid) * 2 + 1], s_mx[tid]);
+    }
+}
+
+// skimage.color.rgb2lab on float32 (colorconv.py rgb2xyz + xyz2lab, D65 / 2 degree observer).
+__device__ __forceinline__ void rgb2lab_f32(float r, float g, float b, float &L, float &A, float &B) {
+    float a[3] = {r, g, b};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = a[c];
+        a[c] = (v > 0.04045f) ? powf((v + 0.055f) / 1.055f, 2.4f) : v / 12.92f;
+    }
+    const float m[3][3] = {{0.412453f, 0.357580f, 0.180423f},
+                           {0.212671f, 0.715160f, 0.072169f},
+                           {0.019334f, 0.119193f, 0.950227f}};
+    const float wr[3] = {0.95047f, 1.0f, 1.08883f};
+    float xyz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float s = a[0] * m[i][0];
+        s = s + a[1] * m[i][1];
+        s = s + a[2] * m[i][2];
+        s = s / wr[i];
+        xyz[i] = (s > 0.008856f) ? cbrtf(s) : 7.787f * s + 16.0f / 116.0f;
+    }
+    L = 116.0f * xyz[1] - 16.0f;
+    A = 500.0f * (xyz[0] - xyz[1]);
+    B = 200.0f * (xyz[1] - xyz[2]);
+}
+
+// K0b: features = [normalize_band] -> [rgb2lab] -> * float32(1/compactness), written to the dense
+// per-problem buffer padded to CP channels (padding is 0: `t = 0 - 0; dc += t*t` leaves every
+// distance bit-identical).  Also reduces max|feature| for the fixed-point scale.  Per-band min and
+// (max - min) are hoisted into registers; C % 4 == 0 rasters are read as float4.
+template <int CP>
+__global__ __launch_bounds__(256) void features_kernel(const float *__restrict__ src, int Ws, int C,
+                                                       const SrcWindow *__restrict__ wins,
+                                                       const unsigned *__restrict__ keys, int normalize,
+                                                       int to_lab, float ratio, float *__restrict__ feat,
+                                                       unsigned *__restrict__ maxabs_bits) {
+    const int p = blockIdx.y;
+    const SrcWindow wdw = wins[p];
+    const long long npix = (long long)wdw.h * wdw.w;
+    float bmn[CP], bden[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        bmn[c] = 0.0f; bden[c] = 1.0f;
+        if (normalize && c < C) {
+            const float mn = key2f(keys[((long long)p * C + c) * 2 + 0]);
+            const float mx = key2f(keys[((long long)p * C + c) * 2 + 1]);
+            bmn[c] = mn; bden[c] = mx - mn;     // (band - min) / (max - min), segment_boundaries.py:16
+        }
+    }
+    const bool vec = (C == CP);                 // C % 4 == 0: aligned float4 reads
+    float local_max = 0.0f;
+    (void)npix;
+    // blocks walk rows, threads walk the pixels of a row: no integer division per pixel
+    for (int y = blockIdx.x; y < wdw.h; y += gridDim.x)
+    for (int x = threadIdx.x; x < wdw.w; x += blockDim.x) {
+        const long long i = (long long)y * wdw.w + x;
+        const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
+        float v[CP];
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < CP / 4; ++q) {
+                const float4 t = reinterpret_cast<const float4 *>(px)[q];
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) v[c] = (c < C) ? px[c] : 0.0f;
+        }
+        if (normalize) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                float t = (v[c] - bmn[c]) / bden[c];
+                if (!(fabsf(t) <= 3.0e38f)) t = 0.0f;   // constant / non-finite band: the problem is rejected on the host
+                v[c] = t;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) if (!(fabsf(v[c]) <= 3.0e38f)) v[c] = 0.0f;
+        }
+        if (to_lab) {
+            float L, A, B;
+            rgb2lab_f32(v[0], v[1], v[2], L, A, B);
+            v[0] = L; v[1] = A; v[2] = B;
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            v[c] = v[c] * ratio;
+            local_max = fmaxf(local_max, fabsf(v[c]));
+        }
+        float4 *dst = reinterpret_cast<float4 *>(feat + (wdw.pix_off + i) * CP);
+#pragma unroll
+        for (int q = 0; q < CP / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    // wave max -> one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxabs_bits, __float_as_uint(local_max));
+}
+
+int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
+                          int to_lab, float ratio, std::vector<int> *skip) {
+    (void)Hs;
+    ScopedSpan span(ctx, T_FEAT);
+    const int C = b.C, np = b.nprob;
+    if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
+    // layout: keys[np][C][2] | nonfinite[np] | maxabs bits
+    const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + np + 1;
+    unsigned *d_keys = ctx->arena.get<unsigned>(ntot);
+    if (!d_keys) return OBIA_E_NOMEM;
+    unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
+    std::vector<unsigned> host(ntot);
+    for (size_t i = 0; i < (size_t)np * C; ++i) { host[2 * i] = 0xffffffffu; host[2 * i + 1] = 0u; }
+    for (size_t i = nkeys; i < ntot; ++i) host[i] = 0;
+    OBIA_HIP_TRY(hipMemcpyAsync(d_keys, host.data(), ntot * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `host` is pageable memory
+    int maxh = 1;
+    long long maxpix = 1;
+    for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; long long n = (long long)w.h * w.w; if (n > maxpix) maxpix = n; }
+    if (normalize) {
+        int gx = maxh < 2048 ? maxh : 2048;
+        // float4 reads need 16-byte aligned rows: C % 4 == 0 and an aligned base pointer
+        if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<4>), dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C,
+                               b.d_windows, d_keys, (int *)d_nonfinite);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<1>), dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C,
+                               b.d_windows, d_keys, (int *)d_nonfinite);
+    }
+    {
+        (void)maxpix;
+        dim3 grid(maxh < 4096 ? maxh : 4096, np);
+#define LAUNCH_FEAT(CPV)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, ctx->stream, src, Ws, C,    \
+                       b.d_windows, d_keys, normalize, to_lab, ratio, b.d_feat, d_maxabs)
+        switch (b.CP) {
+            case 4: LAUNCH_FEAT(4); break;
+            case 8: LAUNCH_FEAT(8); break;
+            case 12: LAUNCH_FEAT(12); break;
+            case 16: LAUNCH_FEAT(16); break;
+            default: set_error("bad CP %d", b.CP); return OBIA_E_INVALID;
+        }
+#undef LAUNCH_FEAT
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    // one read-back: min/max keys (constant-band check), non-finite flags, max|feature|
+    OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));
+    auto k2f = [](unsigned k) { unsigned bb = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &bb, 4); return f; };
+    if (skip) skip->assign(np, 0);
+    if (normalize) {
+        for (int p = 0; p < np; ++p) {
+            bool bad = host[nkeys + p] != 0;
+            int cb = -1;
+            float cv = 0;
+            for (int c = 0; c < C && !bad; ++c) {
+                float mn = k2f(host[((size_t)p * C + c) * 2]), mx = k2f(host[((size_t)p * C + c) * 2 + 1]);
+                if (!(mx > mn)) { cb = c; cv = mn; }
+            }
+            if (bad || cb >= 0) {
+                if (skip) { (*skip)[p] = 1; continue; }
+                if (bad) set_error("input raster holds NaN or infinite values");
+                else set_error("band %d is constant (%g): normalize_band would divide 0 by 0 "
+                               "(obia/segmentation/segment_boundaries.py:16)", cb, (double)cv);
+                return OBIA_E_NONFINITE;
+            }
+        }
+    }
+    float maxabs; unsigned mb = host[nkeys + np]; memcpy(&maxabs, &mb, 4);
+    if (!(maxabs <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
+    // fixed-point scale for the colour sums: totals |feature| * maxcount * 2^s < 2^62, and every partial that is
+    // converted (at most one 128x64 tile of pixels) stays below 2^50 (to_fixed in slic_sweep.hip needs < 2^51)
+    long long maxcount = 1;
+    for (auto &w : b.windows) { long long n = (long long)w.h * w.w; if (n > maxcount) maxcount = n; }
+    double bound = ((double)maxabs + 1e-30) * (double)maxcount;
+    int s = 62 - (int)std::ceil(std::log2(bound + 1.0));
+    const int s2 = 50 - (int)std::ceil(std::log2(((double)maxabs + 1e-30) * (double)(SWEEP_TW * SWEEP_TH) + 1.0));
+    if (s2 < s) s = s2;
+    if (s > 40) s = 40;
+    if (s < -60) s = -60;
+    b.fscale = std::ldexp(1.0, s);
+    return OBIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// seeding
+// ------------------------------------------------------------------------------------------------
+struct SeedGrid { int start_y, step_y, ny, start_x, step_x, nx; int cent_off; int pad; };
+
+// unmasked: centroid k of problem p sits on the regular grid (slic_superpixels.py:71-104)
+__global__ void seed_grid_kernel(const SeedGrid *__restrict__ grids, int nprob, float *__restrict__ seed,
+                                 int *__restrict__ cent_prob) {
+    const int p = blockIdx.y;
+    const SeedGrid g = grids[p];
+    const int K = g.ny * g.nx;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int iy = k / g.nx, ix = k % g.nx;
+        seed[2 * (size_t)(g.cent_off + k)] = (float)(g.start_y + iy * g.step_y);
+        seed[2 * (size_t)(g.cent_off + k) + 1] = (float)(g.start_x + ix * g.step_x);
+        cent_prob[g.cent_off + k] = p;
+    }
+}
+
+// masked: keep the grid points that fall on valid pixels, in row-major order (DESIGN.md "masked-grid
+// seeding"); if none does, seed the first valid pixel.  One workgroup per problem.
+__global__ __launch_bounds__(256) void seed_masked_kernel(const SeedGrid *__restrict__ grids,
+                                                          const SlicProblem *__restrict__ probs,
+                                                          const uint8_t *__restrict__ mask, float *__restrict__ seed,
+                                                          int *__restrict__ cent_prob, int *__restrict__ K_out) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    __shared__ unsigned long long s_first;
+    const int p = blockIdx.x;
+    const SeedGrid g = grids[p];
+    const SlicProblem P = probs[p];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_base = 0; s_first = ~0ull; }
+    __syncthreads();
+    const int Kg = g.ny * g.nx;
+    for (int k0 = 0; k0 < Kg; k0 += 256) {
+        const int k = k0 + tid;
+        int y = 0, x = 0;
+        bool keep = false;
+        if (k < Kg) {
+            y = g.start_y + (k / g.nx) * g.step_y;
+            x = g.start_x + (k % g.nx) * g.step_x;
+            keep = mask[P.pix_off + (long long)y * P.W + x] != 0;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += s_wave[w];
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const int rank = s_base + before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
+            seed[2 * (size_t)(g.cent_off + rank)] = (float)y;
+            seed[2 * (size_t)(g.cent_off + rank) + 1] = (float)x;
+            cent_prob[g.cent_off + rank] = p;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    int K = s_base;
+    if (K == 0) {
+        const long long npix = (long long)P.H * P.W;
+        unsigned long long best = ~0ull;
+        for (long long i = tid; i < npix; i += 256)
+            if (mask[P.pix_off + i]) { best = (unsigned long long)i; break; }
+        atomicMin(&s_first, best);
+        __syncthreads();
+        if (tid == 0 && s_first != ~0ull) {
+            seed[2 * (size_t)g.cent_off] = (float)(s_first / P.W);
+            seed[2 * (size_t)g.cent_off + 1] = (float)(s_first % P.W);
+            cent_prob[g.cent_off] = p;
+        }
+        K = (s_first != ~0ull) ? 1 : 0;
+    }
+    if (tid == 0) K_out[p] = K;
+}
+
+// valid-pixel count per problem (mask.sum(), tiling.py:133 / slic_superpixels.py:322); 16 mask bytes per load
+__global__ __launch_bounds__(256) void count_valid_kernel(const SlicProblem *__restrict__ probs,
+                                                          const uint8_t *__restrict__ mask, int *__restrict__ out) {
+    const int p = blockIdx.y;
+    const SlicProblem P = probs[p];
+    const long long npix = (long long)P.H * P.W;
+    const uint8_t *m = mask + P.pix_off;
+    int c = 0;
+    const long long head = ((16 - (reinterpret_cast<uintptr_t>(m) & 15)) & 15);
+    const long long h0 = head < npix ? head : npix;
+    const long long nvec = (npix - h0) / 16;
+    const uint4 *mv = reinterpret_cast<const uint4 *>(m + h0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 t = mv[i];
+        const unsigned wds[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned nz = wds[q] | (wds[q] >> 4);
+            nz |= nz >> 2; nz |= nz >> 1;
+            c += __popc(nz & 0x01010101u);
+        }
+    }
+    if (blockIdx.x == 0) {   // unaligned head and tail bytes
+        for (long long i = threadIdx.x; i < h0; i += blockDim.x) c += m[i] != 0;
+        for (long long i = h0 + nvec * 16 + threadIdx.x; i < npix; i += blockDim.x) c += m[i] != 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&out[p], c);
+}
+
+int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
+    const int np = b.nprob;
+    Arena &A = ctx->arena;
+    nvalid.assign(np, 0);
+    if (!b.d_probs) b.d_probs = A.get<SlicProblem>(np);
+    if (!b.d_probs) return OBIA_E_NOMEM;
+    if (b.masked) {
+        OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+        int *d_cnt = A.get<int>(np);
+        if (!d_cnt) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * np, ctx->stream));
+        long long maxpix = 1;
+        for (auto &P : b.probs) { long long n = (long long)P.H * P.W; if (n > maxpix) maxpix = n; }
+        int blocks = cdiv(maxpix, 256 * 16 * 4);
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(count_valid_kernel, dim3(blocks, np), dim3(256), 0, ctx->stream, b.d_probs, b.d_mask, d_cnt);
+        OBIA_TRY(read_back(ctx, nvalid.data(), d_cnt, sizeof(int) * np));
+    } else {
+        for (int p = 0; p < np; ++p) nvalid[p] = b.probs[p].H * b.probs[p].W;
+    }
+    return OBIA_OK;
+}
+
+int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments, const std::vector<int> *nvalid_in) {
+    const int np = b.nprob;
+    Arena &A = ctx->arena;
+    // problems carry H, W, pix_off already (set by the caller); upload a first version for the
+    // counting / seeding kernels
+    if (!b.d_probs) b.d_probs = A.get<SlicProblem>(np);
+    if (!b.d_probs) return OBIA_E_NOMEM;
+    std::vector<int> nvalid;
+    if (nvalid_in) nvalid = *nvalid_in;
+    else OBIA_TRY(slic_count_valid(ctx, b, nvalid));
+    std::vector<SeedGrid> grids(np);
+    std::vector<double> stepmax(np);
+    int cent_off = 0;
+    for (int p = 0; p < np; ++p) {
+        SlicProblem &P = b.probs[p];
+        P.n_valid = nvalid[p];
+        SeedGrid &g = grids[p];
+        g.cent_off = cent_off; g.pad = 0;
+        if (nvalid[p] <= 0 || n_segments[p] <= 0) {   // empty problem: no centroids, every pixel stays masked
+            g.start_y = g.start_x = 0; g.step_y = g.step_x = 1; g.ny = g.nx = 0;
+            stepmax[p] = 1.0;
+            P.cent_off = cent_off;
+            continue;
+        }
+        long long n_eff = n_segments[p];
+        if (b.masked) {
+            double ne = std::nearbyint((double)n_segments[p] * ((double)P.H * (double)P.W) / (double)nvalid[p]);
+            n_eff = ne < 1.0 ? 1 : (long long)ne;
+        }
+        long long gr[4];
+        regular_grid_hw(P.H, P.W, n_eff, gr);
+        g.start_y = (int)gr[0]; g.step_y = gr[1] ? (int)gr[1] : 1; g.ny = (int)slice_len(P.H, gr[0], gr[1]);
+        g.start_x = (int)gr[2]; g.step_x = gr[3] ? (int)gr[3] : 1; g.nx = (int)slice_len(P.W, gr[2], gr[3]);
+        double sy = gr[1] ? (double)gr[1] : 1.0, sx = gr[3] ? (double)gr[3] : 1.0;
+        stepmax[p] = sy > sx ? sy : sx;   // max(steps); the depth axis contributes 1.0
+        if (stepmax[p] < 1.0) stepmax[p] = 1.0;
+        P.cent_off = cent_off;
+        long long Kg = (long long)g.ny * g.nx;
+        if (Kg < 1) Kg = 1;   // masked fallback seed
+        if (cent_off + Kg > 0x7fff0000LL) { set_error("too many centroids in one batch"); return OBIA_E_INVALID; }
+        cent_off += (int)Kg;
+    }
+    b.total_cent = cent_off > 0 ? cent_off : 1;
+    b.d_seed = A.get<float>((size_t)b.total_cent * 2);
+    b.d_cent_prob = A.get<int>(b.total_cent);
+    SeedGrid *d_grids = A.get<SeedGrid>(np);
+    if (!b.d_seed || !b.d_cent_prob || !d_grids) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_cent_prob, 0xff, sizeof(int) * b.total_cent, ctx->stream));
+    OBIA_HIP_TRY(hipMemcpyAsync(d_grids, grids.data(), sizeof(SeedGrid) * np, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int> K(np);
+    if (b.masked) {
+        int *d_K = A.get<int>(np);
+        if (!d_K) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(seed_masked_kernel, dim3(np), dim3(256), 0, ctx->stream, d_grids, b.d_probs, b.d_mask,
+                           b.d_seed, b.d_cent_prob, d_K);
+        OBIA_TRY(read_back(ctx, K.data(), d_K, sizeof(int) * np));
+        for (int p = 0; p < np; ++p) if (nvalid[p] <= 0 || n_segments[p] <= 0) K[p] = 0;
+    } else {
+        int maxK = 1;
+        for (int p = 0; p < np; ++p) { K[p] = grids[p].ny * grids[p].nx; if (K[p] > maxK) maxK = K[p]; }
+        hipLaunchKernelGGL(seed_grid_kernel, dim3(cdiv(maxK, 256), np), dim3(256), 0, ctx->stream, d_grids, np,
+                           b.d_seed, b.d_cent_prob);
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // grids/probs host vectors are pageable
+    }
+    // window steps, bins, tiles
+    int cell_off = 0, tile_max = 0;
+    long long tiles_all = 0;
+    for (int p = 0; p < np; ++p) {
+        SlicProblem &P = b.probs[p];
+        P.K = K[p];
+        long long gr[4] = {0, 0, 0, 0};
+        if (P.K > 0) regular_grid_hw(P.H, P.W, P.K, gr);
+        P.sy = gr[1] ? (int)gr[1] : 1;
+        P.sx = gr[3] ? (int)gr[3] : 1;
+        P.ncy = cdiv(P.H, P.sy);
+        P.ncx = cdiv(P.W, P.sx);
+        const float stepf = (float)stepmax[p];
+        P.spatial_w = (float)(1.0 / ((double)stepf * (double)stepf));
+        P.cell_off = cell_off;
+        long long nc = (long long)P.ncy * P.ncx;
+        if (cell_off + nc > 0x7fff0000LL) { set_error("too many bins in one batch"); return OBIA_E_INVALID; }
+        cell_off += (int)nc;
+        P.tiles_x = cdiv(P.W, SWEEP_TW);
+        P.tiles_y = cdiv(P.H, SWEEP_TH);
+        const int nt = P.tiles_x * P.tiles_y;
+        P.tile_off = (int)tiles_all;
+        tiles_all += nt;
+        if (nt > tile_max) tile_max = nt;
+    }
+    b.total_tiles_all = tiles_all > 0 ? tiles_all : 1;
+    b.total_cells = cell_off > 0 ? cell_off : 1;
+    b.total_tiles = tile_max;
+    OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int RS = CENT_REC + b.CP;
+    b.d_cent = A.get<float>((size_t)b.total_cent * RS);
+    b.d_head = A.get<int>((size_t)b.total_cells * 2);
+    b.d_next = A.get<int>(b.total_cent);
+    const size_t acc_q = (size_t)b.total_cent * acc_record_qwords(b.CP);
+    b.d_acc = A.get<unsigned long long>(acc_q);
+    if (!b.d_cent || !b.d_head || !b.d_next || !b.d_acc) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * acc_q, ctx->stream));
+    return OBIA_OK;
+}
+
+}  // namespace obia

@@ -1,0 +1,102 @@
+// slic.hpp -- batched SLIC engine: host-side planning structures and entry points.
+#pragma once
+#include "common.hpp"
+
+namespace obia {
+
+// One independent SLIC problem (a whole image, or one tile window of the tiled driver).
+// Device-visible, read through scalar loads (wave-uniform).
+struct SlicProblem {
+    int H, W;            // window size in pixels
+    int K;               // number of centroids
+    int sy, sx;          // window steps: regular_grid((1,H,W), K) (slic_superpixels.py -> _slic_cython)
+    int ncy, ncx;        // bin grid: cells of sy x sx pixels
+    float spatial_w;     // float(1 / step^2)
+    int cent_off;        // first centroid of this problem in the batch-wide centroid arrays
+    int cell_off;        // first bin of this problem in the batch-wide bin-head array
+    int tile_off;        // first workgroup of this problem in the assign grid
+    int tiles_x, tiles_y;
+    long long pix_off;   // first pixel of this problem in the dense per-problem pixel arrays
+    int n_valid;         // valid (unmasked) pixels
+    int pad;
+};
+
+// Source window of a problem inside the caller's raster (feature preparation).
+struct SrcWindow {
+    int y0, x0, h, w;
+    long long pix_off;
+};
+
+// regular_grid((1,H,W), n) of scikit-image (util/_regular_grid.py:61-83): start/step per axis,
+// step 0 == slice(None).
+void regular_grid_hw(long long H, long long W, long long n, long long out[4]);
+
+constexpr int SWEEP_TW = 64, SWEEP_TH = 64;   // workgroup tile of the sweep kernel (pixels)
+constexpr int CENT_REC = 8;      // header dwords of a centroid record: cy, cx, y0, y1, x0, x1, k, -
+// Accumulator record of one centroid, 128-byte aligned so a tile's flush touches two 64-B lines:
+//   q[0..CP)  colour sums, 64-bit fixed point     q[CP] = n | (sum_y << 32)     q[CP+1] = sum_x
+inline int acc_record_qwords(int CP) { return CP <= 12 ? 16 : 32; }
+
+struct SlicBatch {
+    int nprob = 0;
+    int C = 0, CP = 0;                 // bands, bands padded to a multiple of 4
+    bool masked = false;
+    int start_label = 1;
+    int max_iter = 10;
+    long long total_pix = 0;
+    int total_cent = 0, total_cells = 0, total_tiles = 0;   // total_tiles: largest tile count of one problem (grid.x)
+    long long total_tiles_all = 0;                          // sum over problems (per-tile state of exit_on_fixed_point)
+    std::vector<SlicProblem> probs;    // host copy
+    std::vector<SrcWindow> windows;
+    // device arrays (arena)
+    SlicProblem *d_probs = nullptr;
+    SrcWindow *d_windows = nullptr;
+    float *d_feat = nullptr;           // [total_pix][CP]
+    uint8_t *d_mask = nullptr;         // [total_pix] or null
+    int32_t *d_labels = nullptr;       // [total_pix] problem-local labels (start_label based)
+    float *d_seed = nullptr;           // [total_cent][2]
+    int *d_cent_prob = nullptr;        // [total_cent]
+    float *d_cent = nullptr;           // [total_cent][8 + CP] records
+    int *d_head = nullptr, *d_next = nullptr;   // d_head: two buffers of total_cells (double-buffered per sweep)
+    int *d_head_cur = nullptr;
+    unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
+    double fscale = 1.0;
+    bool exit_on_fixed_point = false;
+};
+
+// Feature preparation for every problem of the batch: per-band min/max of its window, then
+// normalise (optional) -> Lab (optional) -> * 1/compactness into d_feat.  `src` is the caller's
+// (Hs,Ws,C) raster.  Returns OBIA_E_NONFINITE for constant / non-finite bands.
+// `skip` (nullable): when given, a problem whose window holds a constant or non-finite band is flagged
+// skip[p] = 1 (its features are zero) instead of failing the whole batch -- the reference's tiler
+// swallows the per-tile ValueError (tiling.py:149-150).
+int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
+                          int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
+
+// Seeds (grid or masked grid), fills K / steps / bins in b.probs, uploads descriptors.
+// n_segments[p] = requested segments of problem p.
+// nvalid (nullable): valid-pixel counts already known to the caller.
+int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments,
+                       const std::vector<int> *nvalid = nullptr);
+// valid (unmasked) pixels per problem: mask.sum() (tiling.py:133, slic_superpixels.py:322)
+int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid);
+
+// Runs the sweeps; labels (pre-connectivity) land in b.d_labels.
+int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b);
+
+// Connectivity enforcement on a batch of dense label maps laid out back to back (pix_off); labels come
+// out consecutive over the whole batch, in problem order then raster order of each component's first pixel.
+struct CcProblem { int H, W; long long pix_off; int min_size; int pad; };
+int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
+                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out);
+
+// Connectivity enforcement on one dense (H,W) label map (device pointers).
+int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size,
+                             int max_size, int start_label, int32_t *labels_out, int *d_n_labels_out);
+
+// Zonal statistics (device pointers, outputs device).
+int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                    const int32_t *bands_host, int n_bands, int n_labels, int start_label,
+                    int64_t *count, double *mean, double *var, float *mn, float *mx);
+
+}  // namespace obia

@@ -1,0 +1,754 @@
+// slic_sweep.hip -- the per-sweep kernels of the SLIC engine: centroid finalise + binning, and the
+// pixel-centric assign sweep with the centroid update fused in.
+//
+// Restates one iteration of _slic_cython (scikit-image _slic.pyx 0.18.3, reached from
+// obia/segmentation/segment_boundaries.py:51; oracle/obia_oracle.c: obia_oracle_slic_core):
+//   reference: for k ascending: scatter d(k, pixel) into the (4S+1)^2 window of centroid k, keep it where
+//              `distance > d` (ties stay with the lowest k); then sum pixel coordinates and colours per label.
+//   here:      for each pixel: lexicographic minimum of (d, k) over the centroids whose window contains it.
+//              Same candidate set (windows are computed with the reference's float expressions and
+//              truncations), same float32 operation order for d (compiled with -ffp-contract=off), same tie
+//              rule; the sums are exact integers (coordinates) / 64-bit fixed point (colours).
+//
+// Kernel shape (gfx950): one 256-thread workgroup per 128x64 pixel tile.
+//   1. the workgroup stages into LDS the records of every centroid whose window intersects the tile
+//      (lanes walk the per-bin linked lists built by slic_prep_kernel);
+//   2. each wave walks eight 16x16 footprints; a lane owns a 1x4 vertical strip.  Lanes first score the
+//      staged candidates in parallel (one candidate per lane): window-intersects-footprint and a lower
+//      bound `lb` of the spatial term over the footprint; candidates are then visited in ascending lb and
+//      the walk stops when lb exceeds the largest current best distance in the wave (d >= spatial >= lb,
+//      float add/mul are monotone, so nothing that is skipped could have won or tied);
+//   3. the centroid update is fused: per-lane run sums (double) are transposed through a conflict-free LDS
+//      scratch so that 16 lanes x (CP+3) fields fold the wave's 64 strips sequentially, and only the few
+//      resulting (centroid, field) partials touch the workgroup's LDS accumulators (64-bit integer
+//      atomics); one packed global atomic record per (tile, centroid) at the end.
+// A tile that meets more candidates than fit in LDS (tiny S, clustered centroids) takes slow_tile(), which
+// reads the bins directly; correctness never depends on the LDS capacity.
+#include "slic.hpp"
+
+#include <cstdlib>
+
+namespace obia {
+
+#ifdef OBIA_STAMP
+// Diagnostic build only (make STAMP=1): per-phase wave-cycle sums, written to a buffer no other code reads.
+__device__ unsigned long long g_stamp[16];
+#define STAMP_DECL unsigned long long st_t = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) { const unsigned long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 8; ++st_i) atomicAdd(&g_stamp[st_i], st_acc[st_i]); atomicAdd(&g_stamp[15], 1ull); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+constexpr int NT = 256;
+constexpr int FB = 16;          // wave footprint side
+constexpr int PPT = 4;          // pixels per lane (vertical strip)
+constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); 96 keeps 5 workgroups per CU
+
+// K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
+// write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
+// linked list of the bin that holds its current position.  One thread per centroid.
+__global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__restrict__ probs,
+                                                        const int *__restrict__ cent_prob, int total_cent, int CP,
+                                                        int RQ, int first, const float *__restrict__ seed,
+                                                        unsigned long long *__restrict__ acc, double inv_fscale,
+                                                        float *__restrict__ cent, int *__restrict__ head,
+                                                        int *__restrict__ next, int *__restrict__ head_other,
+                                                        int total_cells, int *__restrict__ bin_stamp, int sweep_id) {
+    // exit_on_fixed_point: a centroid whose record differs from the previous sweep's stamps the bin it leaves and the
+    // bin it enters with the sweep number; the sweep kernel skips a tile none of whose bins was stamped since the tile
+    // was last evaluated (same candidate records => same labels, same partial sums, replayed from the tile's cache).
+    // the bin heads are double-buffered: while this sweep fills `head`, the buffer of the NEXT sweep is reset here
+    // (saves one memset launch per sweep)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_cent) return;
+    const int p = cent_prob[k];
+    if (p < 0) return;
+    const SlicProblem P = probs[p];
+    if (k - P.cent_off >= P.K) return;
+    const int RS = CENT_REC + CP;
+    float *rec = cent + (size_t)k * RS;
+    float cy, cx;
+    bool moved = false;
+    const float old_cy = rec[0], old_cx = rec[1];
+    if (first) {
+        cy = seed[2 * (size_t)k];
+        cx = seed[2 * (size_t)k + 1];
+        for (int c = 0; c < CP; ++c) rec[CENT_REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
+        moved = true;
+    } else {
+        unsigned long long *a = acc + (size_t)k * RQ;
+        const unsigned long long ny = a[CP];
+        const unsigned n = (unsigned)(ny & 0xffffffffull);
+        const float fn = (float)n;
+        // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
+        cy = (float)(unsigned)(ny >> 32) / fn;
+        cx = (float)(unsigned)a[CP + 1] / fn;
+        for (int c = 0; c < CP; ++c) {
+            const float s = (float)((double)(long long)a[c] * inv_fscale);
+            const float v = s / fn;
+            moved |= __float_as_uint(v) != __float_as_uint(rec[CENT_REC + c]);
+            rec[CENT_REC + c] = v;
+            a[c] = 0;
+        }
+        a[CP] = 0; a[CP + 1] = 0;
+        moved |= __float_as_uint(cy) != __float_as_uint(rec[0]) || __float_as_uint(cx) != __float_as_uint(rec[1]);
+    }
+    if (bin_stamp && moved && !first && old_cy == old_cy && old_cx == old_cx) {   // the bin it leaves
+        int oby = (int)(old_cy / (float)P.sy), obx = (int)(old_cx / (float)P.sx);
+        oby = oby < 0 ? 0 : (oby >= P.ncy ? P.ncy - 1 : oby);
+        obx = obx < 0 ? 0 : (obx >= P.ncx ? P.ncx - 1 : obx);
+        bin_stamp[P.cell_off + oby * P.ncx + obx] = sweep_id;
+    }
+    rec[0] = cy; rec[1] = cx;
+    int *irec = reinterpret_cast<int *>(rec);
+    irec[6] = k; irec[7] = 0;
+    if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
+        irec[2] = 0; irec[3] = 0; irec[4] = 0; irec[5] = 0;
+        next[k] = -1;
+        return;
+    }
+    // z/y/x window of _slic_cython: (ssize_t)max(c - 2*step, 0) .. (ssize_t)min(c + 2*step + 1, size)
+    float fy0 = cy - (float)(2 * P.sy); fy0 = (0.0f > fy0) ? 0.0f : fy0;
+    float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
+    float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
+    float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
+    irec[2] = (int)fy0; irec[3] = (int)fy1; irec[4] = (int)fx0; irec[5] = (int)fx1;
+    int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
+    by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
+    bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
+    next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+    if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
+}
+
+// double -> 64-bit fixed point, round to nearest even.  |v * fscale| < 2^51 (the scale is chosen for that in
+// slic_prepare_features), so adding 1.5 * 2^52 leaves the integer in the low mantissa bits: one FMA and one
+// 64-bit subtract instead of the ~10-instruction conversion sequence.
+__device__ __forceinline__ unsigned long long to_fixed(double v, double fscale) {
+    const double magic = 6755399441055744.0;   // 2^52 + 2^51
+    const double t = __fma_rn(v, fscale, magic);
+    return (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(magic));
+}
+
+// ---- wave-wide reductions on DPP (no LDS traffic) ---------------------------------------------------
+// non-negative floats order like their bit patterns, so min/max run on unsigned integers.  Written as
+// inline asm so that every butterfly step is ONE v_{min,max}_u32 with a DPP operand (hipcc lowers the
+// update_dpp builtin to v_mov + v_mov_dpp + v_min, three VALU issues per step).  A DPP operand written by
+// the previous VALU instruction needs two wait states: the s_nop 1 in front of every step.
+#define OBIA_WAVE_REDUCE(OP)                                                                      \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"      \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_nop 1"                                                                        \
+                 : "+v"(v))
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    OBIA_WAVE_REDUCE("v_max_u32_dpp");   // every lane now holds the maximum of its row of 16
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+    OBIA_WAVE_REDUCE("v_min_u32_dpp");
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// LDS written by some lanes of a wave and read by other lanes of the same wave: the LDS pipe executes a
+// wave's instructions in order, so only the COMPILER must be kept from moving accesses across this point.
+// (A workgroup-scope fence would also emit s_waitcnt vmcnt(0) and stall on the label stores in flight.)
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int CP>
+__device__ __forceinline__ void global_accumulate(unsigned long long *__restrict__ acc, int RQ, int k, unsigned n,
+                                                  unsigned sumy, unsigned long long sumx, const double *sf,
+                                                  double fscale) {
+    unsigned long long *a = acc + (size_t)k * RQ;
+#pragma unroll
+    for (int ch = 0; ch < CP; ++ch) atomicAdd(&a[ch], to_fixed(sf[ch], fscale));
+    atomicAdd(&a[CP], (unsigned long long)n | ((unsigned long long)sumy << 32));
+    atomicAdd(&a[CP + 1], sumx);
+}
+
+// Fallback for a tile whose candidate set does not fit the LDS slots: every lane scans the bins around
+// each of its pixels directly in global memory.  Same arithmetic, no staging.
+template <int CP, bool MASKED, bool IGNORE_COLOR>
+__device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *__restrict__ feat,
+                          const uint8_t *__restrict__ mask, const float *__restrict__ cent,
+                          const int *__restrict__ head, const int *__restrict__ next, int32_t *__restrict__ labels,
+                          unsigned long long *__restrict__ acc, int RQ, int accumulate, int start_label, double fscale) {
+    constexpr int RS = CENT_REC + CP;
+    const float w = P.spatial_w;
+    for (int i = threadIdx.x; i < SWEEP_TW * SWEEP_TH; i += NT) {
+        const int y = ty0 + i / SWEEP_TW, x = tx0 + i % SWEEP_TW;
+        if (y >= P.H || x >= P.W) continue;
+        const long long pix = P.pix_off + (long long)y * P.W + x;
+        if (MASKED && mask[pix] == 0) { labels[pix] = start_label - 1; continue; }
+        float f[CP];
+#pragma unroll
+        for (int ch = 0; ch < CP; ++ch) f[ch] = feat[pix * CP + ch];
+        int by_lo = (y - 2 * P.sy - 2) / P.sy; if (y - 2 * P.sy - 2 < 0) by_lo = 0;
+        int by_hi = (y + 2 * P.sy + 2) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
+        int bx_lo = (x - 2 * P.sx - 2) / P.sx; if (x - 2 * P.sx - 2 < 0) bx_lo = 0;
+        int bx_hi = (x + 2 * P.sx + 2) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
+        float best = INFINITY;
+        int bk = -1;
+        for (int by = by_lo; by <= by_hi; ++by)
+            for (int bx = bx_lo; bx <= bx_hi; ++bx)
+                for (int cur = head[P.cell_off + by * P.ncx + bx]; cur >= 0; cur = next[cur]) {
+                    const float *rec = cent + (size_t)cur * RS;
+                    const int *irec = reinterpret_cast<const int *>(rec);
+                    if (!(y >= irec[2] && y < irec[3] && x >= irec[4] && x < irec[5])) continue;
+                    const float tyv = rec[0] - (float)y, txv = rec[1] - (float)x;
+                    const float dy2 = tyv * tyv, dx2 = txv * txv;
+                    float d = (dy2 + dx2) * w;
+                    if (!IGNORE_COLOR) {
+                        float dc = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) { const float t = f[ch] - rec[CENT_REC + ch]; dc += t * t; }
+                        d += dc;
+                    }
+                    if (d < best || (d == best && cur < bk)) { best = d; bk = cur; }
+                }
+        int k = bk;
+        if (k < 0) {   // `nearest` keeps the previous sweep's value
+            const int prev = labels[pix];
+            if (prev >= start_label) k = prev - start_label + P.cent_off;
+        } else {
+            labels[pix] = k - P.cent_off + start_label;
+        }
+        if (accumulate && k >= 0) {
+            double sf[CP];
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) sf[ch] = (double)f[ch];
+            global_accumulate<CP>(acc, RQ, k, 1u, (unsigned)y, (unsigned long long)x, sf, fscale);
+        }
+    }
+}
+
+// K2: the sweep.  grid = (max tiles per problem, nprob).
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(
+    const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
+    const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
+    int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,
+    int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
+    int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
+    unsigned long long *__restrict__ px_counter) {
+    // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
+    // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
+    // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
+    const SlicProblem P = probs[blockIdx.y];
+    const int tile = blockIdx.x;
+    if (tile >= P.tiles_x * P.tiles_y) return;
+    constexpr int RS = CENT_REC + CP;
+    constexpr int AQ = CP + 1;                  // qwords of an LDS accumulator: colours, then one packed word
+                                                //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 128x64 tile: n <= 8192,
+                                                //   sums <= 8192 * 127 < 2^20: no field can carry into the next)
+    constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
+
+    __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
+    __shared__ __attribute__((aligned(16))) float s_col[MAXC][CP];
+    __shared__ unsigned long long s_acc[MAXC][AQ];
+    __shared__ double s_tf[NT / 64][CP][65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ int s_tkey[NT / 64][64];
+    __shared__ int s_cnt, s_uncacheable;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ty0 = (tile / P.tiles_x) * SWEEP_TH, tx0 = (tile % P.tiles_x) * SWEEP_TW;
+    const int ty1 = min(ty0 + SWEEP_TH, P.H), tx1 = min(tx0 + SWEEP_TW, P.W);
+
+    STAMP_DECL
+    // ---- wave geometry; the features of the wave's FIRST footprint are requested before staging, so their HBM
+    // latency overlaps the dependent bin -> record loads of the staging phase ---------------------------------------
+    const float w = P.spatial_w;
+    const int fy0 = ty0 + FB * wv;
+    const bool wave_active = fy0 < P.H;   // a wave below the bottom edge only helps with the final flush
+    const int fy1 = min(fy0 + FB, P.H);
+    const int yb = fy0 + PPT * (lane >> 4);
+    const bool want_feat = !IGNORE_COLOR || accum_color;
+    float f[PPT][CP];
+    bool valid[PPT];
+    auto fetch = [&](int fx0) {
+        const int xx = fx0 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int y = yb + j;
+            bool v = (y < P.H) && (xx < P.W);
+            const long long pix = P.pix_off + (long long)y * P.W + xx;
+            if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
+            valid[j] = v;
+            if (v && want_feat) {
+                const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) {
+                    const float4 t = src[q];
+                    f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
+            }
+        }
+    };
+    if (!FIXPT && wave_active) fetch(tx0);
+    constexpr int GQ = CP + 2;   // global record / cache entry: colours, n | sum_y << 32, sum_x
+    const int tile_id = P.tile_off + tile;
+    // bins whose centroids can reach the tile: candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with
+    // y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H)) that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel
+    // of slack covers float rounding of the binning.
+    int by_lo = (ty0 - 2 * P.sy - 2) / P.sy; if (ty0 - 2 * P.sy - 2 < 0) by_lo = 0;
+    int by_hi = (ty1 + 2 * P.sy + 1) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
+    int bx_lo = (tx0 - 2 * P.sx - 2) / P.sx; if (tx0 - 2 * P.sx - 2 < 0) bx_lo = 0;
+    int bx_hi = (tx1 + 2 * P.sx + 1) / P.sx; if (bx_hi > P.ncx - 1) bx_hi = P.ncx - 1;
+    const int nbw = bx_hi - bx_lo + 1;
+    const int nbins = (by_hi - by_lo + 1) * nbw;
+    if (FIXPT) {
+        // exit_on_fixed_point: has any bin that can feed this tile been stamped since the tile was last evaluated?
+        const int lp = use_cache ? tile_lp[tile_id] : 0;
+        int dirty = lp <= 0;
+        if (!dirty)
+            for (int bi = tid; bi < nbins; bi += NT)
+                dirty |= bin_stamp[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw] > lp;
+        if (!__syncthreads_or(dirty)) {
+            // same candidate records as when the cache was written: same labels (already in place), same partial
+            // sums -- replay them (cache_k[.][0] holds the slot count, -1 marks a slot nothing landed on)
+            if (accumulate) {
+                const int *ck = cache_k + (size_t)tile_id * (MAXC + 1);
+                const unsigned long long *cq = cache_q + (size_t)tile_id * MAXC * GQ;
+                const int ne = ck[0];
+                for (int i = tid; i < ne * GQ; i += NT) {
+                    const int e = i / GQ, q = i - e * GQ;
+                    const int k = ck[1 + e];
+                    if (k < 0 || (q < CP && !accum_color)) continue;
+                    atomicAdd(&acc[(size_t)k * RQ + q], cq[(size_t)e * GQ + q]);
+                }
+            }
+            return;
+        }
+        if (px_counter && tid == 0) atomicAdd(&px_counter[tile & 255], (unsigned long long)(ty1 - ty0) * (unsigned long long)(tx1 - tx0));
+    } else if (px_counter && tile == 0 && tid == 0) {
+        atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
+    }
+    for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
+    if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
+    __syncthreads();
+
+    if (FIXPT && wave_active) fetch(tx0);
+
+    // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
+    {
+        for (int bi = tid; bi < nbins; bi += NT) {
+            int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
+            while (cur >= 0) {
+                // one round trip per list node: the whole record and the link are requested together
+                const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
+                const float4 r0 = src[0], r1 = src[1];
+                float4 rc[CP / 4];
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) rc[q] = src[2 + q];
+                const int nxt = next[cur];
+                const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
+                const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
+                if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
+                    const int slot = atomicAdd(&s_cnt, 1);
+                    if (slot < MAXC) {
+                        float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
+                        dh[0] = r0; dh[1] = r1;
+                        float4 *dc = reinterpret_cast<float4 *>(&s_col[slot][0]);
+#pragma unroll
+                        for (int q = 0; q < CP / 4; ++q) dc[q] = rc[q];
+                    }
+                }
+                cur = nxt;
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(0)   // staging
+    const int nc = s_cnt;
+    if (nc > MAXC) {   // wave-uniform (whole workgroup)
+        slow_tile<CP, MASKED, IGNORE_COLOR>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
+                                            start_label, fscale);
+        return;
+    }
+
+    // ---- 2. per wave: eight 16x16 footprints (one 16-row band of the 128x64 tile) ----------------------------------------------------------------------
+    for (int bxi = 0; wave_active && bxi < SWEEP_TW / FB; ++bxi) {
+        const int fx0 = tx0 + FB * bxi;
+        if (fx0 >= P.W) break;   // wave-uniform
+        const int fx1 = min(fx0 + FB, P.W);
+        const int x = fx0 + (lane & 15);
+        const float fx = (float)x;
+        if (bxi > 0) fetch(fx0);
+        // best_d of an invalid pixel is -inf: nothing is ever smaller, so the visits need no `valid` test
+        float best_d[PPT], fyv[PPT];
+        int best_s[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) { best_d[j] = valid[j] ? INFINITY : -INFINITY; best_s[j] = -1; fyv[j] = (float)(yb + j); }
+
+        // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
+        // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
+        // operation is monotone, so lb <= spatial(pixel) <= d(pixel) for every pixel of the footprint.
+        unsigned lbv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = 64 * r + lane;
+            unsigned key = 0xffffffffu;
+            if (c < nc) {
+                const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
+                const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+                const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
+                const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
+                if (y0 < fy1 && y1 > fy0 && x0 < fx1 && x1 > fx0) {
+                    const float cy = h0.x, cx = h0.y;
+                    const float ry = (cy < (float)fy0) ? (float)fy0 : ((cy > (float)(fy1 - 1)) ? (float)(fy1 - 1) : cy);
+                    const float rx = (cx < (float)fx0) ? (float)fx0 : ((cx > (float)(fx1 - 1)) ? (float)(fx1 - 1) : cx);
+                    const float tyv = cy - ry, txv = cx - rx;
+                    const float lb = (tyv * tyv + txv * txv) * w;
+                    key = __float_as_uint(lb);      // lb >= 0: bit pattern order == value order; never 0xffffffff
+                }
+            }
+            lbv[r] = key;
+        }
+
+        STAMP(2)   // scoring
+        // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
+        unsigned maxbest = 0x7f800000u;   // +inf
+        for (;;) {
+            const unsigned mn = wave_umin(min(lbv[0], lbv[1]));
+            if (mn == 0xffffffffu || mn > maxbest) break;   // equality must still be visited: it can tie on k
+            int c;
+            {
+                const unsigned long long b0 = __ballot(lbv[0] == mn);
+                if (b0) { c = __ffsll((long long)b0) - 1; if (lane == c) lbv[0] = 0xffffffffu; }
+                else {
+                    const unsigned long long b1 = __ballot(lbv[1] == mn);
+                    c = __ffsll((long long)b1) - 1;
+                    if (lane == c) lbv[1] = 0xffffffffu;
+                    c += 64;
+                }
+            }
+            // the candidate's header is wave-uniform: keep it in scalar registers
+            const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
+            const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+            const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h0.x)));
+            const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h0.y)));
+            const int y0 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.z)), y1 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.w));
+            const int x0 = __builtin_amdgcn_readfirstlane(__float_as_int(h1.x)), x1 = __builtin_amdgcn_readfirstlane(__float_as_int(h1.y));
+            const int kk = __builtin_amdgcn_readfirstlane(__float_as_int(h1.z));
+            // a window that covers the whole footprint (the common case: windows are ~4S wide) needs no per-pixel test
+            const bool covers = (y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1);
+            const float tx = cx - fx;
+            const float dx2 = tx * tx;
+            const bool inx = covers || ((x >= x0) && (x < x1));
+            float dv[PPT];
+            bool cand[PPT];     // this candidate may still win or tie this pixel
+            bool any = false, improved = false;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const float tyv = cy - fyv[j];
+                const float dy2 = tyv * tyv;
+                dv[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
+                // colour >= 0 and float add is monotone, so d >= spatial: a candidate whose spatial part already
+                // exceeds the best distance cannot win (equality could still tie on k)
+                bool cnd = !(dv[j] > best_d[j]);
+                if (!covers) cnd = cnd && inx && ((unsigned)(yb + j - y0) < (unsigned)(y1 - y0));
+                cand[j] = cnd;
+                any |= cnd;
+            }
+            if (any) {
+                if (!IGNORE_COLOR) {
+                    float col[CP];
+#pragma unroll
+                    for (int q = 0; q < CP / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
+                        col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j) {
+                        float dc = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) {
+                            const float t = f[j][ch] - col[ch];
+                            dc += t * t;
+                        }
+                        dv[j] += dc;
+                    }
+                }
+                // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k).  Exact ties are
+                // rare: the strict comparison is the fast path, ties are resolved on k only when one occurred.
+                bool tie = false;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const bool lt = cand[j] && (dv[j] < best_d[j]);
+                    tie |= cand[j] && (dv[j] == best_d[j]);
+                    improved |= lt;
+                    best_d[j] = lt ? dv[j] : best_d[j];
+                    best_s[j] = lt ? c : best_s[j];
+                }
+                if (tie) {
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j) {
+                        if (cand[j] && dv[j] == best_d[j] && best_s[j] != c && dv[j] < INFINITY) {   // `inf > inf` never assigns
+                            const int bk = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : 0x7fffffff;
+                            if (kk < bk) best_s[j] = c;
+                        }
+                    }
+                }
+            }
+            // largest best distance in the wave (+inf while a valid pixel is unassigned; invalid pixels hold -inf);
+            // it can only have moved if some lane improved
+            if (__ballot(improved)) {
+                const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
+                maxbest = wave_umax(__float_as_uint(lm));
+            }
+        }
+        STAMP(3)   // visits
+        int best_k[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) best_k[j] = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : -1;
+
+        // ---- labels ---------------------------------------------------------------------------------------------------
+        int pk[PPT];   // accumulation key: LDS slot, or -1
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int y = yb + j;
+            const bool inimg = (y < P.H) && (x < P.W);
+            const long long pix = P.pix_off + (long long)y * P.W + x;
+            pk[j] = (valid[j] && best_s[j] >= 0) ? best_s[j] : -1;
+            if (!inimg) continue;
+            if (valid[j] && best_s[j] < 0) {
+                // no window reaches this pixel: `nearest` keeps the previous sweep's value (it is only initialised
+                // once, before the loop) and the pixel is accumulated under it
+                const int prev = labels[pix];
+                if (FIXPT) s_uncacheable = 1;   // this tile's result depends on the previous labels: never replay it
+                if (prev >= start_label && accumulate) {
+                    double one[CP];
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) one[ch] = (double)f[j][ch];
+                    global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, 1u, (unsigned)y,
+                                          (unsigned long long)x, one, fscale);
+                }
+            } else {
+                labels[pix] = (best_s[j] >= 0) ? (best_k[j] - P.cent_off + start_label) : (start_label - 1);
+            }
+        }
+        STAMP(4)   // labels
+        if (!accumulate) continue;
+
+        // ---- 3. fused centroid update ------------------------------------------------------------------------------------
+        // Integer part (n, sum_y, sum_x): one packed 64-bit LDS atomic per run, tile-relative coordinates.
+        // Colour part: per-lane runs of equal slot over the strip, summed in double (exact for 4 floats); the FIRST run
+        // of every lane goes through the transposed fold below, later runs (a strip crossing a segment boundary) go
+        // straight to the LDS accumulators.
+        if (accum_color) s_tkey[wv][lane] = -1;
+        {
+            const unsigned long long xrel = (unsigned long long)(x - tx0);
+            int rkey = -1, nruns = 0;
+            unsigned rn = 0, ry = 0;
+            double rf[CP];
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+            auto close_run = [&]() {
+                if (rkey < 0) return;
+                atomicAdd(&s_acc[rkey][CP], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
+                if (accum_color) {
+                    if (nruns == 0) {   // the lane's slot in the transposed scratch
+                        s_tkey[wv][lane] = rkey;
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) s_tf[wv][ch][lane] = rf[ch];
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][ch], to_fixed(rf[ch], fscale));
+                    }
+                }
+                ++nruns;
+            };
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                if (pk[j] != rkey) {
+                    close_run();
+                    rkey = pk[j]; rn = 0; ry = 0;
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+                }
+                if (pk[j] >= 0) {
+                    rn += 1; ry += (unsigned)(yb + j - ty0);
+                    if (accum_color) {
+#pragma unroll
+                        for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
+                    }
+                }
+            }
+            close_run();
+        }
+        STAMP(5)   // run merge
+        if (!accum_color) continue;   // wave-uniform: spatial-only pre-pass sweeps fold no colours
+        // transposed fold: lane (fld, g) folds the 8 strips 8g .. 8g+7 of colour field fld
+        wave_lds_sync();
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int fld = 8 * pass + (lane & 7), g = lane >> 3;
+            if (fld < CP) {
+                int cur = -1;
+                double sum = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int src = 8 * g + i;
+                    const int key = s_tkey[wv][src];
+                    const double v = key >= 0 ? s_tf[wv][fld][src] : 0.0;   // strips without a run left stale data
+                    if (key != cur) {
+                        if (cur >= 0) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
+                        cur = key; sum = 0.0;
+                    }
+                    sum += v;
+                }
+                if (cur >= 0) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
+            }
+        }
+        wave_lds_sync();   // the scratch is rewritten by the next footprint
+        STAMP(6)   // fold
+    }
+    if (!accumulate) { STAMP_FLUSH return; }
+    __syncthreads();
+    // ---- LDS accumulators -> global records: consecutive lanes write consecutive qwords of one 128-B record -----------
+    // (with exit_on_fixed_point the same values are kept, slot by slot, as the tile's cache for the sweeps that replay them)
+    const bool keep = FIXPT && !s_uncacheable;
+    int *ck = keep ? cache_k + (size_t)tile_id * (MAXC + 1) : nullptr;
+    unsigned long long *cq = keep ? cache_q + (size_t)tile_id * MAXC * GQ : nullptr;
+    for (int i = tid; i < nc * GQ; i += NT) {
+        const int slot = i / GQ, q = i - slot * GQ;
+        const unsigned long long pw = s_acc[slot][CP];
+        const unsigned long long n = pw & 0xffffull;
+        if (FIXPT && keep && q == 0) ck[1 + slot] = n ? __float_as_int(s_hdr[slot][6]) : -1;
+        if (n == 0ull) continue;   // nothing landed on this centroid
+        const int k = __float_as_int(s_hdr[slot][6]);
+        unsigned long long v;
+        if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][q] : 0ull; }
+        else if (q == CP) v = n | ((((pw >> 16) & 0xffffffull) + n * (unsigned long long)ty0) << 32);
+        else v = (pw >> 40) + n * (unsigned long long)tx0;
+        if (FIXPT && keep) cq[(size_t)slot * GQ + q] = v;
+        if (FIXPT && q < CP && !accum_color) continue;
+        atomicAdd(&acc[(size_t)k * RQ + q], v);
+    }
+    if (keep && tid == 0) { ck[0] = nc; tile_lp[tile_id] = sweep_id; }
+    STAMP(7)   // barrier + flush
+    STAMP_FLUSH
+}
+
+#ifdef OBIA_STAMP
+extern "C" void obia_debug_stamps(unsigned long long *out16, int reset) {
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+}
+#endif
+
+struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; null when the option is off)
+    int *bin_stamp = nullptr, *tile_lp = nullptr, *cache_k = nullptr;
+    unsigned long long *cache_q = nullptr;
+};
+
+template <int CP>
+static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color,
+                          const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
+    dim3 grid(b.total_tiles, b.nprob);
+    static const int ablate = getenv("OBIA_ABLATE") ? atoi(getenv("OBIA_ABLATE")) : 0;   // timing experiments only
+    if (ablate & 1) accumulate = 0;
+    const int RQ = acc_record_qwords(CP);
+#define LAUNCH_ASSIGN_(M, I, F)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
+                       accum_color, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,   \
+                       use_cache, px_counter)
+#define LAUNCH_ASSIGN(M, I) do { if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true); else LAUNCH_ASSIGN_(M, I, false); } while (0)
+    if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
+    else LAUNCH_ASSIGN(false, false);
+#undef LAUNCH_ASSIGN
+#undef LAUNCH_ASSIGN_
+}
+
+__global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
+    // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
+    {
+        long long n = b.total_pix;
+        int blocks = cdiv(n, 256 * 8);
+        if (blocks > 65535) blocks = 65535;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
+    }
+    if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
+    const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
+    const int RQ = acc_record_qwords(b.CP);
+    Arena &A = ctx->arena;
+    // pixel counters (profiling): 256 slots each for the colour sweeps and the pre-pass sweeps, summed on the host
+    unsigned long long *d_px = ctx->profiling ? A.get<unsigned long long>(512) : nullptr;
+    if (ctx->profiling && !d_px) return OBIA_E_NOMEM;
+    if (d_px) OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 512, ctx->stream));
+    FixedPointState fp;
+    if (b.exit_on_fixed_point) {
+        const size_t nt = (size_t)b.total_tiles_all;
+        fp.bin_stamp = A.get<int>((size_t)b.total_cells);
+        fp.tile_lp = A.get<int>(nt);
+        fp.cache_k = A.get<int>(nt * (MAXC + 1));
+        fp.cache_q = A.get<unsigned long long>(nt * MAXC * (size_t)(b.CP + 2));
+        if (!fp.bin_stamp || !fp.tile_lp || !fp.cache_k || !fp.cache_q) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(fp.bin_stamp, 0, sizeof(int) * (size_t)b.total_cells, ctx->stream));
+        OBIA_HIP_TRY(hipMemsetAsync(fp.tile_lp, 0, sizeof(int) * nt, ctx->stream));
+    }
+    bool first = true;
+    int sweep_no = 0;
+    OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
+    for (int pass = 0; pass < passes; ++pass) {
+        const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
+        const bool last_pass = (pass == passes - 1);
+        for (int it = 0; it < b.max_iter; ++it) {
+            int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
+            int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
+            ++sweep_no;   // sweep ids start at 1
+            hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
+                               b.d_cent_prob, b.total_cent, b.CP, RQ, first ? 1 : 0, b.d_seed, b.d_acc, 1.0 / b.fscale,
+                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+            b.d_head_cur = head_cur;
+            first = false;
+            // the update after the very last sweep is never read: skip its accumulation
+            const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
+            const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
+            // the last pre-pass sweep is the only one of its pass that folds colours (they seed the main pass): the
+            // caches written by the earlier pre-pass sweeps hold no colour sums, so it evaluates every tile
+            const int use_cache = (ignore_color && it == b.max_iter - 1) ? 0 : 1;
+            {
+                ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
+                unsigned long long *pxc = d_px ? d_px + (ignore_color ? 256 : 0) : nullptr;
+                switch (b.CP) {
+                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
+                    default: set_error("bad CP"); return OBIA_E_INVALID;
+                }
+            }
+        }
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    if (d_px) {
+        unsigned long long h[512];
+        OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
+        for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
+    }
+    return OBIA_OK;
+}
+
+}  // namespace obia

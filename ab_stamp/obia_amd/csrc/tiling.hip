@@ -1,0 +1,506 @@
+// tiling.hip -- B3: the tiled driver on label rasters.
+//
+// Restates the two tile loops of obia.utils.tiling.create_tiled_segments (tiling.py:103-291), where the
+// reference keeps two growing GeoDataFrames and tests every accumulated polygon against every white tile
+// with shapely predicates (tiling.py:205-231).  Here the state is one global label raster G (0 = no
+// segment) plus a per-segment pixel count, and the predicates are pixel counts:
+//   within(tile_polygon)   <=>  every pixel of the segment lies inside the grown window minus the two
+//                               bottom corner squares           (count inside == segment size)
+//   overlaps(tile_polygon) <=>  some but not all of its pixels do
+// (segments are 4-connected pixel sets, tile_polygon is pixel-aligned, rasterize() uses the pixel-centre
+// rule, so the pixel statements are exactly the polygon statements).
+//   pass 1  "black" tiles ((i/T + j/T) even), exact windows          tiling.py:103-153
+//   pass 2  "white" tiles, windows grown by `buffer` and clamped      tiling.py:156-172
+//           segments within the polygon are dropped and re-segmented  tiling.py:220-231
+//           segments overlapping it are kept and masked out, together with the corner squares
+//                                                                    tiling.py:213-260
+//           n_segments = round(mask.sum() * pixel_area / (pi * crown_radius^2))   tiling.py:126-135
+//   ids 1..N in the order black (survivors), then white              tiling.py:289-290
+// All tiles of a pass (or of one white tile-row) are ONE batch for the SLIC engine and for the
+// connectivity kernels: no per-tile launches, two host read-backs per batch.
+#include "slic.hpp"
+
+#include <cmath>
+
+namespace obia {
+
+struct TileWin { int y0, x0, h, w; long long pix_off; int cly, clx; };   // window, dense offset, corner square (px)
+
+// wave-aggregated histogram add: lanes of a wave that hold the same key add once
+__device__ __forceinline__ void wave_hist_add(unsigned *hist, int key, bool active) {
+    bool todo = active;
+    while (true) {
+        const unsigned long long act = __ballot(todo);
+        if (!act) break;
+        const int leader = __ffsll((long long)act) - 1;
+        const int kk = __shfl(key, leader);
+        const unsigned long long same = __ballot(todo && key == kk);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[kk], (unsigned)__popcll(same));
+        if (key == kk) todo = false;
+    }
+}
+
+__device__ __forceinline__ bool in_corner(const TileWin &t, int y, int x) {
+    return (y >= t.h - t.cly) && (x < t.clx || x >= t.w - t.clx);
+}
+
+// white tiles, step 1: pixels of every existing segment that lie inside the tile polygon
+__global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ G,
+                                                                int Wr, unsigned *__restrict__ inside) {
+    const TileWin t = wins[blockIdx.y];
+    const int wround = ((t.w + 255) / 256) * 256;   // whole waves stay in the loop for the wave-level histogram
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+        for (int x0 = 0; x0 < wround; x0 += 256) {
+            const int x = x0 + threadIdx.x;
+            int g = 0;
+            if (x < t.w && !in_corner(t, y, x)) g = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+            wave_hist_add(inside, g, g > 0);
+        }
+}
+
+// step 2: dense tile mask.  black: the input mask.  white: input mask minus kept (overlapping) segments
+// minus the corner squares; segments within the polygon are erased from G (they will be re-segmented).
+__global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restrict__ wins, const uint8_t *__restrict__ inmask,
+                                                        int32_t *__restrict__ G, int Wr, int white,
+                                                        const unsigned *__restrict__ inside, const unsigned *__restrict__ seg_size,
+                                                        uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask) {
+    const TileWin t = wins[blockIdx.y];
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+    for (int x = threadIdx.x; x < t.w; x += blockDim.x) {
+        const long long i = (long long)y * t.w + x;
+        const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
+        uint8_t m = inmask ? (inmask[gp] != 0) : 1;
+        if (white) {
+            if (in_corner(t, y, x)) m = 0;
+            else {
+                const int g = G[gp];
+                if (g > 0) {
+                    if (inside[g] == seg_size[g]) { G[gp] = 0; alive[g] = 0; }   // within: dropped
+                    else m = 0;                                                    // overlaps: kept, masked out
+                }
+            }
+        }
+        dmask[t.pix_off + i] = m;
+    }
+}
+
+// step 3: write the new segments of the batch into G with their provisional global ids + size histogram
+__global__ __launch_bounds__(256) void tile_scatter_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ lab,
+                                                           int32_t *__restrict__ G, int Wr, int id_base,
+                                                           unsigned *__restrict__ seg_size) {
+    const TileWin t = wins[blockIdx.y];
+    const int wround = ((t.w + 255) / 256) * 256;
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+        for (int x0 = 0; x0 < wround; x0 += 256) {
+            const int x = x0 + threadIdx.x;
+            int id = 0;
+            if (x < t.w) {
+                const int l = lab[t.pix_off + (long long)y * t.w + x];
+                if (l > 0) {
+                    id = id_base + l;
+                    G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id;
+                }
+            }
+            wave_hist_add(seg_size, id, id > 0);
+        }
+}
+
+// final ids 1..N: exclusive scan over the alive flags of the provisional ids.  Single workgroup (the id table is
+// ~1e6 entries), chunked so that every load is a coalesced 16-byte read.
+__global__ __launch_bounds__(1024) void ids_scan_kernel(const uint8_t *__restrict__ alive, int n_ids, int *__restrict__ newid,
+                                                        long long *__restrict__ total) {
+    __shared__ int s_wave[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < n_ids; base += 1024 * 16) {
+        const int i0 = base + tid * 16;
+        unsigned char f[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) f[q] = (i0 + q < n_ids) ? alive[i0 + q] : 0;
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c += f[q] != 0;
+        // inclusive scan of c over the wave (shuffle up), then over the 16 waves
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        int before = s_run;
+        for (int w2 = 0; w2 < wv; ++w2) before += s_wave[w2];
+        int run = before + inc - c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (i0 + q < n_ids) { if (f[q]) { run += 1; newid[i0 + q] = run; } else newid[i0 + q] = 0; }
+        __syncthreads();
+        if (tid == 1023) s_run = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_run;
+}
+
+__global__ void ids_apply_kernel(int32_t *__restrict__ G, long long n, const int *__restrict__ newid) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int g = G[i];
+        G[i] = g > 0 ? newid[g] : 0;
+    }
+}
+
+struct TileState {
+    int H, W, C;            // local raster: rows [row0, row0 + H) of a (Hg, W) raster
+    int Hg, row0;
+    const float *img;
+    const uint8_t *inmask;
+    int32_t *G;
+    unsigned *seg_size, *inside;
+    uint8_t *alive;
+    int *newid;
+    long long *d_total;
+    int id_cap, next_id;   // provisional ids 1..next_id-1
+    int clx, cly;          // corner square (pixels)
+    obia_tiling_params tp;
+    obia_slic_params sp;
+};
+
+static int grid_rows(const std::vector<TileWin> &wins) {   // row-walking kernels: one block per row (capped)
+    int g = 1;
+    for (auto &t : wins) if (t.h > g) g = t.h;
+    return g > 8192 ? 8192 : g;
+}
+
+// One batch of tiles: mask -> features -> plan -> sweeps -> connectivity -> scatter.
+static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &wins, bool white) {
+    const int np = (int)wins.size();
+    if (np == 0) return OBIA_OK;
+    Arena &A = ctx->arena;
+    const Arena::Mark mk = A.mark();
+    SlicBatch b;
+    b.nprob = np;
+    b.C = S.C;
+    b.CP = (S.C + 3) & ~3;
+    b.masked = true;       // the tiler always hands a mask to slic (tiling.py:137-143): maskSLIC structure
+    b.start_label = 1;
+    b.max_iter = S.sp.max_num_iter;
+    b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
+    long long off = 0, maxpix = 1;
+    b.probs.resize(np);
+    b.windows.resize(np);
+    for (int p = 0; p < np; ++p) {
+        wins[p].pix_off = off;
+        SlicProblem P{};
+        P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off;
+        b.probs[p] = P;
+        b.windows[p] = SrcWindow{wins[p].y0, wins[p].x0, wins[p].h, wins[p].w, off};
+        const long long n = (long long)wins[p].h * wins[p].w;
+        if (n > maxpix) maxpix = n;
+        off += n;
+    }
+    if (off > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
+    b.total_pix = off;
+    TileWin *d_wins = A.get<TileWin>(np);
+    b.d_windows = A.get<SrcWindow>(np);
+    b.d_mask = A.get<uint8_t>((size_t)off);
+    b.d_feat = A.get<float>((size_t)off * b.CP);
+    b.d_labels = A.get<int32_t>((size_t)off);
+    int32_t *d_final = A.get<int32_t>((size_t)off);
+    if (!d_wins || !b.d_windows || !b.d_mask || !b.d_feat || !b.d_labels || !d_final) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemcpyAsync(d_wins, wins.data(), sizeof(TileWin) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipMemcpyAsync(b.d_windows, b.windows.data(), sizeof(SrcWindow) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (white) {
+        OBIA_HIP_TRY(hipMemsetAsync(S.inside, 0, sizeof(unsigned) * (size_t)S.next_id, ctx->stream));
+        hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
+    }
+    hipLaunchKernelGGL(tile_mask_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask, S.G, S.W,
+                       white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+    // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
+    std::vector<int> skip;
+    const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
+    OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp.compactness), &skip));
+    std::vector<int> nvalid;
+    OBIA_TRY(slic_count_valid(ctx, b, nvalid));
+    std::vector<int> nseg(np);
+    const double pixel_area = S.tp.pixel_width * S.tp.pixel_height;
+    const double crown_area = M_PI * S.tp.crown_radius * S.tp.crown_radius;
+    for (int p = 0; p < np; ++p) {
+        double n;
+        if (S.sp.n_segments > 0)   // extension: explicit n_segments per full tile, scaled by the valid area
+            n = std::nearbyint((double)S.sp.n_segments * (double)nvalid[p] / ((double)S.tp.tile_size * S.tp.tile_size));
+        else
+            n = std::nearbyint((double)nvalid[p] * pixel_area / crown_area);   // Python round(): half to even
+        nseg[p] = (skip[p] || n < 1.0) ? 0 : (n > 2.0e9 ? 2000000000 : (int)n);   // empty tile -> skipped (tiling.py:149-150)
+    }
+    OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, &nvalid));
+    OBIA_TRY(slic_run_sweeps(ctx, b));
+    int n_new = 0;
+    if (S.sp.enforce_connectivity) {
+        std::vector<CcProblem> cps(np);
+        for (int p = 0; p < np; ++p) {
+            const SlicProblem &P = b.probs[p];
+            const double segment_size = P.K > 0 ? (double)P.n_valid / (double)P.K : 1.0;
+            cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp.min_size_factor * segment_size), 0};
+        }
+        OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new));
+    } else {
+        set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)");
+        return OBIA_E_UNSUPPORTED;
+    }
+    if (S.next_id + n_new > S.id_cap) { set_error("segment id capacity exceeded (%d + %d > %d)", S.next_id, n_new, S.id_cap); return OBIA_E_NOMEM; }
+    if (n_new > 0) {
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, d_final, S.G, S.W,
+                           S.next_id - 1, S.seg_size);
+        OBIA_HIP_TRY(hipMemsetAsync(S.alive + S.next_id, 1, (size_t)n_new, ctx->stream));
+        S.next_id += n_new;
+    }
+    OBIA_HIP_TRY(hipGetLastError());
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // host vectors of this batch go out of scope
+    A.rewind(mk);
+    return OBIA_OK;
+}
+
+static int tiler_check(const float *img, int H, int W, int C, int Hg, int row0, const obia_tiling_params *tp,
+                       const obia_slic_params *sp, const int32_t *labels) {
+    if (!img || !tp || !sp || !labels) { set_error("null argument"); return OBIA_E_INVALID; }
+    if (H <= 0 || W <= 0 || C <= 0 || C > 16) { set_error("bad raster shape (%d,%d,%d)", H, W, C); return OBIA_E_INVALID; }
+    if (row0 < 0 || row0 + H > Hg) { set_error("local rows [%d,%d) outside the global raster of %d rows", row0, row0 + H, Hg); return OBIA_E_INVALID; }
+    if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels: shard it across GPUs"); return OBIA_E_INVALID; }
+    if (tp->tile_size <= 0 || tp->buffer < 0) { set_error("tile_size must be positive and buffer non-negative"); return OBIA_E_INVALID; }
+    if (!(sp->compactness > 0.0) || sp->max_num_iter < 0) { set_error("bad SLIC parameters"); return OBIA_E_INVALID; }
+    if (sp->slic_zero) { set_error("slic_zero=True is not implemented in this version"); return OBIA_E_UNSUPPORTED; }
+    if (!sp->enforce_connectivity) { set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)"); return OBIA_E_UNSUPPORTED; }
+    if (sp->n_segments <= 0 && !(tp->crown_radius > 0.0 && tp->pixel_width > 0.0 && tp->pixel_height > 0.0)) {
+        set_error("crown_radius and pixel size must be positive when n_segments is not given");
+        return OBIA_E_INVALID;
+    }
+    return OBIA_OK;
+}
+
+static int tiler_init(obia_ctx *ctx, TileState &S, const float *img, const uint8_t *mask, int H, int W, int C, int Hg,
+                      int row0, const obia_tiling_params *tp, const obia_slic_params *sp, int32_t *labels, int extra_ids) {
+    OBIA_TRY(tiler_check(img, H, W, C, Hg, row0, tp, sp, labels));
+    const int T = tp->tile_size, B = tp->buffer;
+    Arena &A = ctx->arena;
+    // capacity for provisional ids: every tile can create at most its grid of seeds
+    const int ntx = cdiv(W, T), nty = cdiv(H, T) + 2;
+    const double pixel_area = tp->pixel_width * tp->pixel_height;
+    const double crown_area = M_PI * tp->crown_radius * tp->crown_radius;
+    const long long wh = (long long)(T + 2 * B) * (T + 2 * B);
+    double n = sp->n_segments > 0 ? (double)sp->n_segments * (double)wh / ((double)T * T) : (double)wh * pixel_area / crown_area;
+    if (n < 1) n = 1;
+    // masked seeding lays a grid for n_eff ~ n over the window; rounding of the step can add ~(1 + 1/S)^2
+    long long cap = (long long)(n * 1.5 + 64.0) * (long long)ntx * nty + 16 + extra_ids;
+    if (cap > 0x7ffffff0LL) { set_error("too many segments for int32 ids"); return OBIA_E_INVALID; }
+    S.H = H; S.W = W; S.C = C; S.Hg = Hg; S.row0 = row0; S.img = img; S.inmask = mask; S.G = labels; S.tp = *tp; S.sp = *sp;
+    S.id_cap = (int)cap; S.next_id = 1;
+    S.seg_size = A.get<unsigned>((size_t)cap);
+    S.inside = A.get<unsigned>((size_t)cap);
+    S.alive = A.get<uint8_t>((size_t)cap);
+    S.newid = A.get<int>((size_t)cap);
+    S.d_total = A.get<long long>(1);
+    if (!S.seg_size || !S.inside || !S.alive || !S.newid || !S.d_total) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(S.seg_size, 0, sizeof(unsigned) * (size_t)cap, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(S.alive, 0, (size_t)cap, ctx->stream));
+    // corner squares: side buffer/2 in MAP units (tiling.py:189), i.e. buffer/2/pixel_size pixels; a pixel is
+    // inside when its centre is (rasterize default all_touched=False)
+    S.clx = S.cly = 0;
+    if (B > 0) {
+        const double cl = (double)B / 2.0;
+        S.clx = (int)std::ceil(cl / (tp->pixel_width > 0 ? tp->pixel_width : 1.0) - 0.5);
+        S.cly = (int)std::ceil(cl / (tp->pixel_height > 0 ? tp->pixel_height : 1.0) - 0.5);
+        if (S.clx < 0) S.clx = 0;
+        if (S.cly < 0) S.cly = 0;
+    }
+    return OBIA_OK;
+}
+
+// Tiles of GLOBAL tile rows [tr_lo, tr_hi) with (tr % 2 == parity) when parity is 0 or 1.  Black tiles: exact
+// windows, one batch for the whole range.  White tiles: windows grown by `buffer` and clamped to the GLOBAL
+// raster, one batch per tile-row (windows of one tile-row never overlap; those of adjacent rows overlap at
+// corners).  Every window must lie inside the local rows.
+static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_hi, int parity) {
+    const int T = S.tp.tile_size, B = S.tp.buffer;
+    const int ntx = cdiv(S.W, T), nty = cdiv(S.Hg, T);
+    if (tr_lo < 0) tr_lo = 0;
+    if (tr_hi > nty) tr_hi = nty;
+    std::vector<TileWin> wins;
+    auto flush = [&]() -> int {
+        for (auto &t : wins)
+            if (t.y0 < 0 || t.y0 + t.h > S.H) { set_error("tile window rows [%d,%d) (local) outside the %d local rows: halo too small", t.y0, t.y0 + t.h, S.H); return OBIA_E_INVALID; }
+        int rc = run_tile_batch(ctx, S, wins, white);
+        wins.clear();
+        return rc;
+    };
+    for (int tj = tr_lo; tj < tr_hi; ++tj) {
+        if (parity >= 0 && (tj & 1) != parity) continue;
+        for (int ti = 0; ti < ntx; ++ti) {
+            const bool is_white = (ti + tj) % 2 != 0;
+            if (is_white != white) continue;
+            if (!white) {
+                TileWin t{tj * T - S.row0, ti * T, std::min(T, S.Hg - tj * T), std::min(T, S.W - ti * T), 0, 0, 0};
+                if (t.h > 0 && t.w > 0) wins.push_back(t);
+            } else {
+                const int y0 = std::max(0, tj * T - B), y1 = std::min(S.Hg, tj * T + T + B);
+                const int x0 = std::max(0, ti * T - B), x1 = std::min(S.W, ti * T + T + B);
+                TileWin t{y0 - S.row0, x0, y1 - y0, x1 - x0, 0, std::min(S.cly, y1 - y0), std::min(S.clx, x1 - x0)};
+                if (t.h > 0 && t.w > 0) wins.push_back(t);
+            }
+        }
+        if (white) OBIA_TRY(flush());
+    }
+    if (!white) OBIA_TRY(flush());
+    return OBIA_OK;
+}
+
+// ids 1..N: black survivors first, then white, each in creation order (tiling.py:289-290)
+static int tiler_finalize(obia_ctx *ctx, TileState &S, int64_t *n_segments_out) {
+    hipLaunchKernelGGL(ids_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.alive, S.next_id, S.newid, S.d_total);
+    int g = cdiv((long long)S.H * S.W, 256 * 8);
+    if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(ids_apply_kernel, dim3(g), dim3(256), 0, ctx->stream, S.G, (long long)S.H * S.W, S.newid);
+    OBIA_HIP_TRY(hipGetLastError());
+    long long total = 0;
+    OBIA_TRY(read_back(ctx, &total, S.d_total, sizeof(long long)));
+    if (n_segments_out) *n_segments_out = total;
+    return OBIA_OK;
+}
+
+static int tiled_slic_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
+                          const obia_tiling_params *tp, const obia_slic_params *sp, int32_t *labels_out,
+                          int64_t *n_segments_out) {
+    TileState S;
+    OBIA_TRY(tiler_init(ctx, S, img, mask, H, W, C, H, 0, tp, sp, labels_out, 0));
+    OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * (size_t)H * W, ctx->stream));
+    const int nty = cdiv(H, tp->tile_size);
+    OBIA_TRY(tiler_run(ctx, S, false, 0, nty, -1));                       // pass 1: black tiles
+    if (tp->white_order == 1) {                                           // pass 2, two parity classes of tile rows
+        OBIA_TRY(tiler_run(ctx, S, true, 0, nty, 0));
+        OBIA_TRY(tiler_run(ctx, S, true, 0, nty, 1));
+    } else {
+        OBIA_TRY(tiler_run(ctx, S, true, 0, nty, -1));                    // pass 2, the reference's raster order
+    }
+    return tiler_finalize(ctx, S, n_segments_out);
+}
+
+}  // namespace obia
+
+struct obia_tiler {
+    obia_ctx *ctx;
+    obia::TileState S;
+};
+
+using namespace obia;
+
+extern "C" {
+
+obia_tiler *obia_tiler_create(obia_ctx *ctx, const float *img_local, const uint8_t *mask_local, int H_local, int W, int C,
+                              int H_global, int row0, const obia_tiling_params *tiling, const obia_slic_params *params,
+                              int32_t *labels_local, int extra_ids) {
+    if (!ctx) { set_error("null context"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    obia_tiler *t = new obia_tiler();
+    t->ctx = ctx;
+    if (tiler_init(ctx, t->S, img_local, mask_local, H_local, W, C, H_global, row0, tiling, params, labels_local,
+                   extra_ids < 0 ? 0 : extra_ids) != OBIA_OK) { delete t; return nullptr; }
+    return t;
+}
+
+void obia_tiler_destroy(obia_tiler *t) {
+    if (!t) return;
+    (void)hipStreamSynchronize(t->ctx->stream);
+    resolve_timing(t->ctx);
+    delete t;
+}
+
+int obia_tiler_run(obia_tiler *t, int white, int tile_row_lo, int tile_row_hi, int row_parity) {
+    if (!t) { set_error("null tiler"); return OBIA_E_INVALID; }
+    if (hipSetDevice(t->ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
+    OBIA_TRY(tiler_run(t->ctx, t->S, white != 0, tile_row_lo, tile_row_hi, row_parity));
+    OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
+int obia_tiler_next_id(obia_tiler *t) { return t ? t->S.next_id : -1; }
+
+int obia_tiler_set_segments(obia_tiler *t, int first_id, int count, const uint32_t *sizes_dev) {
+    if (!t || !sizes_dev || first_id < 1 || count < 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    if (first_id + count > t->S.id_cap) { set_error("segment id capacity exceeded (%d + %d > %d)", first_id, count, t->S.id_cap); return OBIA_E_NOMEM; }
+    if (count == 0) return OBIA_OK;
+    OBIA_HIP_TRY(hipMemcpyAsync(t->S.seg_size + first_id, sizes_dev, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, t->ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(t->S.alive + first_id, 1, (size_t)count, t->ctx->stream));
+    if (first_id + count > t->S.next_id) t->S.next_id = first_id + count;
+    OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
+int obia_tiler_get_alive(obia_tiler *t, uint8_t *alive_out_dev, int count) {
+    if (!t || !alive_out_dev || count < 0 || count > t->S.id_cap) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    OBIA_HIP_TRY(hipMemcpyAsync(alive_out_dev, t->S.alive, (size_t)count, hipMemcpyDeviceToDevice, t->ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
+int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count) {
+    if (!t || !alive_in_dev || count < 0 || count > t->S.id_cap) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    OBIA_HIP_TRY(hipMemcpyAsync(t->S.alive, alive_in_dev, (size_t)count, hipMemcpyDeviceToDevice, t->ctx->stream));
+    OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
+int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out) {
+    if (!t) { set_error("null tiler"); return OBIA_E_INVALID; }
+    return tiler_finalize(t->ctx, t->S, n_segments_out);
+}
+
+int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
+                            const obia_tiling_params *tiling, const obia_slic_params *params, int32_t *labels_out,
+                            int64_t *n_segments_out) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    int rc;
+    {
+        ScopedSpan total(ctx, T_TOTAL);
+        rc = tiled_slic_dev(ctx, img, mask, H, W, C, tiling, params, labels_out, n_segments_out);
+    }
+    if (rc != OBIA_OK) return rc;
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    return OBIA_OK;
+}
+
+int obia_tiled_slic_f32(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
+                        const obia_tiling_params *tiling, const obia_slic_params *params, int32_t *labels_out,
+                        int64_t *n_segments_out) {
+    if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
+    if (!img || !labels_out || H <= 0 || W <= 0 || C <= 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
+    const size_t npix = (size_t)H * W;
+    float *d_img = nullptr; uint8_t *d_mask = nullptr; int32_t *d_lab = nullptr;
+    int rc = OBIA_OK;
+    if (hipMalloc(&d_img, npix * C * sizeof(float)) != hipSuccess || hipMalloc(&d_lab, npix * sizeof(int32_t)) != hipSuccess ||
+        (mask && hipMalloc(&d_mask, npix) != hipSuccess)) {
+        set_error("device allocation for host-pointer call failed");
+        rc = OBIA_E_NOMEM;
+    }
+    if (rc == OBIA_OK && hipMemcpyAsync(d_img, img, npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK && mask && hipMemcpyAsync(d_mask, mask, npix, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_E_HIP) set_error("host->device copy failed in obia_tiled_slic_f32");
+    if (rc == OBIA_OK) rc = obia_tiled_slic_f32_dev(ctx, d_img, d_mask, H, W, C, tiling, params, d_lab, n_segments_out);
+    if (rc == OBIA_OK && hipMemcpyAsync(labels_out, d_lab, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+        set_error("device->host copy failed in obia_tiled_slic_f32");
+        rc = OBIA_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_img); (void)hipFree(d_lab); (void)hipFree(d_mask);
+    return rc;
+}
+
+}  // extern "C"

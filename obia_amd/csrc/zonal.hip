@@ -9,7 +9,13 @@
 
 namespace obia {
 
-constexpr int Z_TILE = 64, Z_NT = 256, Z_FB = 16, Z_PPT = 4, Z_SLOTS = 64, Z_MAXB = 16;
+#ifndef ZW
+#define ZW 8
+#endif
+#ifndef ZR
+#define ZR 2
+#endif
+constexpr int Z_TILE = 64, Z_SLOTS = 64, Z_MAXB = 16, Z_ROWS = ZR;
 
 struct BandList { int n; int b[Z_MAXB]; };
 
@@ -22,149 +28,146 @@ __device__ __forceinline__ float zunkey(unsigned k) {
     return __uint_as_float(b);
 }
 
-__device__ __forceinline__ void zonal_wave_sync() {   // same-wave LDS hand-off: compiler barrier only (LDS is in order per wave)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// One workgroup per 64x64 tile; each wave walks four 16x16 footprints, a lane owns a 1x4 vertical strip.
-//   per lane : runs of equal label over the strip are summed in registers (sum, sum of squares in double; min, max)
-//   per wave : the FIRST run of every lane goes through a transposed LDS scratch so that lane (field, group) folds 16
-//              strips sequentially -- the 64 lanes of a footprint carry only a handful of labels, so direct LDS atomics
-//              would serialise on the same addresses; later runs of a lane (strip crossing a label boundary) and NaN
-//              bookkeeping use direct LDS atomics
-//   per tile : a 64-slot LDS hash table keyed by label collects the partials; one global atomic per
-//              (tile, label, band, statistic) at the end.  A tile that holds more than 64 labels sends the overflow
-//              straight to global memory.
-// NBP: band count rounded up (4, 8, 16) so the per-lane run state stays in registers.
+// One workgroup per 64x64 tile.  A lane owns FOUR bands of ONE pixel column: lane = (column, band quad), LPP = NBP / 4
+// lanes per pixel, so the 64 lanes of a wave read 64 consecutive 16-byte chunks of a raster row (one 1-KB request) and a
+// workgroup of LPP waves covers the 64 columns.  Every lane walks its column down the 64 rows of the tile:
+//   per lane : runs of equal label down the column are summed in registers (sum, sum of squares in double; min, max) --
+//              24 registers of state, so the loads of the next Z_ROWS rows are in flight while the current ones are
+//              folded, and 8 waves per SIMD fit
+//   per run  : the partial goes to a 64-slot LDS hash table keyed by label (native ds_add_f64 / ds_min_u32 / ds_max_u32);
+//              a column crosses a segment boundary every ~S rows, so a lane closes ~4 runs per tile
+//   per tile : one global atomic per (tile, label, band, statistic) at the end.  A tile that holds more than 64 labels
+//              sends the overflow straight to global memory.
 template <int NBP>
-__global__ __launch_bounds__(Z_NT) void zonal_kernel(const float *__restrict__ raw, const int32_t *__restrict__ labels,
-                                                     int H, int W, int C, BandList bl, int n_labels, int start_label,
-                                                     unsigned *__restrict__ g_cnt, unsigned *__restrict__ g_nan,
-                                                     double *__restrict__ g_sum, double *__restrict__ g_sq,
-                                                     unsigned *__restrict__ g_mn, unsigned *__restrict__ g_mx) {
+__global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_kernel(const float *__restrict__ raw, const int32_t *__restrict__ labels,
+                                                         int H, int W, int C, BandList bl, int n_labels, int start_label,
+                                                         unsigned *__restrict__ g_cnt, unsigned *__restrict__ g_nan,
+                                                         double *__restrict__ g_sum, double *__restrict__ g_sq,
+                                                         unsigned *__restrict__ g_mn, unsigned *__restrict__ g_mx) {
+    constexpr int LPP = NBP / 4, NT = 64 * LPP;
     __shared__ int s_key[Z_SLOTS];
     __shared__ unsigned s_cnt[Z_SLOTS];
     __shared__ unsigned s_nan[Z_SLOTS][NBP];
     __shared__ double s_sum[Z_SLOTS][NBP], s_sq[Z_SLOTS][NBP];
     __shared__ unsigned s_mn[Z_SLOTS][NBP], s_mx[Z_SLOTS][NBP];
-    __shared__ double s_td[Z_NT / 64][2 * NBP][65];    // transposed scratch: sums then squares (reused for min / max keys)
-    __shared__ int s_tslot[Z_NT / 64][64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const int nb = bl.n;
-    for (int i = tid; i < Z_SLOTS; i += Z_NT) { s_key[i] = -1; s_cnt[i] = 0; }
-    for (int i = tid; i < Z_SLOTS * NBP; i += Z_NT) {
+    for (int i = tid; i < Z_SLOTS; i += NT) { s_key[i] = -1; s_cnt[i] = 0; }
+    for (int i = tid; i < Z_SLOTS * NBP; i += NT) {
         (&s_sum[0][0])[i] = 0.0; (&s_sq[0][0])[i] = 0.0; (&s_nan[0][0])[i] = 0u;
         (&s_mn[0][0])[i] = 0xffffffffu; (&s_mx[0][0])[i] = 0u;
     }
     __syncthreads();
     const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
     const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
-    const int fy0 = ty0 + Z_FB * wv;
-    const bool vec = (C % 4 == 0) && (nb == C);   // all bands in order: float4 loads
+    const int x = tx0 + tid / LPP, q = tid % LPP;       // column, band quad
+    const bool vec = (C % 4 == 0) && (nb == C);         // all bands in order: one float4 per lane and row
+    const bool col_ok = x < W;
+    int bsel[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)   // constant indices only: the band list stays in scalar registers
+        bsel[b] = (q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b];
+    const int nbq = min(4, max(0, nb - 4 * q));         // bands of this lane's quad that exist
 
+    int c_lab = -2, c_slot = -1;                        // one-entry cache of the last label -> slot lookup
     auto find_slot = [&](int l) -> int {
+        if (l == c_lab) return c_slot;
         const unsigned h = ((unsigned)l * 2654435761u) >> 26;
+        int found = -1;
+#pragma unroll 1
         for (int probe = 0; probe < Z_SLOTS; ++probe) {
             const int sidx = (h + probe) & (Z_SLOTS - 1);
             const int old = atomicCAS(&s_key[sidx], -1, l);
-            if (old == -1 || old == l) return sidx;
+            if (old == -1 || old == l) { found = sidx; break; }
         }
-        return -1;
+        c_lab = l; c_slot = found;
+        return found;
     };
 
-    for (int bxi = 0; bxi < Z_TILE / Z_FB && fy0 < H; ++bxi) {
-        const int fx0 = tx0 + Z_FB * bxi;
-        if (fx0 >= W) break;
-        const int x = fx0 + (lane & 15), yb = fy0 + Z_PPT * (lane >> 4);
-        // ---- per-lane runs -----------------------------------------------------------------------------------------
-        int rl = -1, nruns = 0, slot0 = -1;
-        unsigned rn = 0;
-        double rs[NBP], rq[NBP];
-        float rmn[NBP], rmx[NBP];
+    int rl = -1;
+    unsigned rn = 0;
+    double rs[4], rq[4];
+    float rmn[4], rmx[4];
 #pragma unroll
-        for (int b = 0; b < NBP; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
-        auto close_run = [&]() {
-            if (rl < 0) return;
-            const int slot = find_slot(rl);
-            if (slot >= 0) {
-                atomicAdd(&s_cnt[slot], rn);
-                if (nruns == 0) {   // hand the partial to the transposed fold
-                    slot0 = slot;
+    for (int b = 0; b < 4; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
+    auto close_run = [&]() {
+        if (rl < 0) return;
+        const int slot = find_slot(rl);
+        if (slot >= 0) {
+            if (q == 0) atomicAdd(&s_cnt[slot], rn);
 #pragma unroll
-                    for (int b = 0; b < NBP; ++b) { s_td[wv][b][lane] = rs[b]; s_td[wv][NBP + b][lane] = rq[b]; }
-                } else {
-#pragma unroll
-                    for (int b = 0; b < NBP; ++b) {
-                        if (b >= nb) continue;
-                        atomicAdd(&s_sum[slot][b], rs[b]);
-                        atomicAdd(&s_sq[slot][b], rq[b]);
-                    }
-                }
-                if (nruns != 0) {
-#pragma unroll
-                    for (int b = 0; b < NBP; ++b) {
-                        if (b >= nb) continue;
-                        atomicMin(&s_mn[slot][b], zkey(rmn[b]));
-                        atomicMax(&s_mx[slot][b], zkey(rmx[b]));
-                    }
-                }
-            } else {   // table full (more than 64 labels in one tile): straight to global memory
-                atomicAdd(&g_cnt[rl], rn);
-#pragma unroll
-                for (int b = 0; b < NBP; ++b) {
-                    if (b >= nb) continue;
-                    unsafeAtomicAdd(&g_sum[(size_t)rl * nb + b], rs[b]);
-                    unsafeAtomicAdd(&g_sq[(size_t)rl * nb + b], rq[b]);
-                    if (rmn[b] <= rmx[b]) {
-                        atomicMin(&g_mn[(size_t)rl * nb + b], zkey(rmn[b]));
-                        atomicMax(&g_mx[(size_t)rl * nb + b], zkey(rmx[b]));
-                    }
-                }
+            for (int b = 0; b < 4; ++b) {
+                if (b >= nbq || !(rmn[b] <= rmx[b])) continue;   // band absent, or only NaNs in this run
+                atomicAdd(&s_sum[slot][4 * q + b], rs[b]);
+                atomicAdd(&s_sq[slot][4 * q + b], rq[b]);
+                atomicMin(&s_mn[slot][4 * q + b], zkey(rmn[b]));
+                atomicMax(&s_mx[slot][4 * q + b], zkey(rmx[b]));
             }
-            ++nruns;
-        };
-        float pmn[NBP], pmx[NBP];   // min / max of the lane's first run (folded after the sums)
+        } else {   // table full (more than 64 labels in one tile): straight to global memory
+            if (q == 0) atomicAdd(&g_cnt[rl], rn);
 #pragma unroll
-        for (int b = 0; b < NBP; ++b) { pmn[b] = INFINITY; pmx[b] = -INFINITY; }
+            for (int b = 0; b < 4; ++b) {
+                if (b >= nbq || !(rmn[b] <= rmx[b])) continue;
+                const size_t o = (size_t)rl * nb + 4 * q + b;
+                unsafeAtomicAdd(&g_sum[o], rs[b]);
+                unsafeAtomicAdd(&g_sq[o], rq[b]);
+                atomicMin(&g_mn[o], zkey(rmn[b]));
+                atomicMax(&g_mx[o], zkey(rmx[b]));
+            }
+        }
+    };
+
+    // rows in groups of Z_ROWS: the loads of group g+1 are issued before group g is folded
+    int lab[2][Z_ROWS];
+    float4 val[2][Z_ROWS];
+    auto fetch = [&](int buf, int y0) {
 #pragma unroll
-        for (int j = 0; j < Z_PPT; ++j) {
-            const int y = yb + j;
+        for (int j = 0; j < Z_ROWS; ++j) {
+            const int y = y0 + j;
             int l = -1;
-            if (y < H && x < W) {
-                l = labels[(long long)y * W + x] - start_label;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (col_ok && y < H) {
+                const long long pix = (long long)y * W + x;
+                l = labels[pix] - start_label;
                 if (l < 0 || l >= n_labels) l = -1;
-            }
-            if (l != rl) {
-                if (nruns == 0 && rl >= 0) {
-#pragma unroll
-                    for (int b = 0; b < NBP; ++b) { pmn[b] = rmn[b]; pmx[b] = rmx[b]; }
-                }
-                close_run();
-                rl = l; rn = 0;
-#pragma unroll
-                for (int b = 0; b < NBP; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
-            }
-            if (l >= 0) {
-                const float *px = raw + ((long long)y * W + x) * C;
-                float v[NBP];
-                if (vec) {
-#pragma unroll
-                    for (int q = 0; q < NBP / 4; ++q) {
-                        if (4 * q < nb) {
-                            const float4 t = reinterpret_cast<const float4 *>(px)[q];
-                            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-                        } else { v[4 * q] = v[4 * q + 1] = v[4 * q + 2] = v[4 * q + 3] = 0.0f; }
+                if (l >= 0 && nbq > 0) {
+                    const float *px = raw + pix * C;
+                    if (vec) v = reinterpret_cast<const float4 *>(px)[q];
+                    else {
+                        v.x = px[bsel[0]];
+                        if (nbq > 1) v.y = px[bsel[1]];
+                        if (nbq > 2) v.z = px[bsel[2]];
+                        if (nbq > 3) v.w = px[bsel[3]];
                     }
-                } else {
-#pragma unroll
-                    for (int b = 0; b < NBP; ++b) v[b] = (b < nb) ? px[bl.b[b]] : 0.0f;
                 }
-                rn += 1;
+            }
+            lab[buf][j] = l; val[buf][j] = v;
+        }
+    };
+    const int y_end = min(ty0 + Z_TILE, H);
+    fetch(0, ty0);
+#pragma unroll 1
+    for (int g = 0; g < Z_TILE / Z_ROWS; g += 2) {
 #pragma unroll
-                for (int b = 0; b < NBP; ++b) {
-                    if (b >= nb) continue;
+        for (int half = 0; half < 2; ++half) {
+            const int y0 = ty0 + (g + half) * Z_ROWS;
+            if (y0 >= y_end) break;                      // workgroup-uniform
+            fetch(half ^ 1, y0 + Z_ROWS);                // rows past the tile or the raster come back as label -1
+#pragma unroll
+            for (int j = 0; j < Z_ROWS; ++j) {
+                const int l = (y0 + j < y_end) ? lab[half][j] : -1;
+                if (l != rl) {
+                    close_run();
+                    rl = l; rn = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
+                }
+                if (l < 0) continue;
+                rn += 1;
+                const float v[4] = {val[half][j].x, val[half][j].y, val[half][j].z, val[half][j].w};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b >= nbq) continue;
                     if (v[b] == v[b]) {
                         const double dv = (double)v[b];
                         rs[b] += dv; rq[b] += dv * dv;
@@ -173,71 +176,16 @@ __global__ __launch_bounds__(Z_NT) void zonal_kernel(const float *__restrict__ r
                         // NaN pixels are dropped per band (`band[~isnan]`, segment_statistics.py:145-147): remember how
                         // many, the per-band count is (label count - NaN count).  Rare: direct atomics.
                         const int slot = find_slot(l);
-                        if (slot >= 0) atomicAdd(&s_nan[slot][b], 1u);
-                        else atomicAdd(&g_nan[(size_t)l * nb + b], 1u);
+                        if (slot >= 0) atomicAdd(&s_nan[slot][4 * q + b], 1u);
+                        else atomicAdd(&g_nan[(size_t)l * nb + 4 * q + b], 1u);
                     }
                 }
             }
         }
-        if (nruns == 0 && rl >= 0) {
-#pragma unroll
-            for (int b = 0; b < NBP; ++b) { pmn[b] = rmn[b]; pmx[b] = rmx[b]; }
-        }
-        close_run();
-        s_tslot[wv][lane] = slot0;
-        // ---- transposed fold of the first runs: lane (fld, g) folds strips 16g .. 16g+15 of field fld -----------------
-        zonal_wave_sync();
-#pragma unroll
-        for (int pass = 0; pass < (2 * NBP + 15) / 16; ++pass) {
-            const int fld = 16 * pass + (lane & 15), g = lane >> 4;
-            const int b = fld < NBP ? fld : fld - NBP;
-            if (fld < 2 * NBP && b < nb) {
-                int cur = -1;
-                double sum = 0.0;
-                for (int i = 0; i < 16; ++i) {
-                    const int src = 16 * g + i;
-                    const int key = s_tslot[wv][src];
-                    const double v = key >= 0 ? s_td[wv][fld][src] : 0.0;
-                    if (key != cur) {
-                        if (cur >= 0) atomicAdd(fld < NBP ? &s_sum[cur][b] : &s_sq[cur][b], sum);
-                        cur = key; sum = 0.0;
-                    }
-                    sum += v;
-                }
-                if (cur >= 0) atomicAdd(fld < NBP ? &s_sum[cur][b] : &s_sq[cur][b], sum);
-            }
-        }
-        zonal_wave_sync();
-        // min / max keys through the same scratch (as 32-bit words)
-        unsigned *tk = reinterpret_cast<unsigned *>(&s_td[wv][0][0]);   // [2*NBP][130] words
-#pragma unroll
-        for (int b = 0; b < NBP; ++b) { tk[b * 130 + lane] = zkey(pmn[b]); tk[(NBP + b) * 130 + lane] = zkey(pmx[b]); }
-        zonal_wave_sync();
-#pragma unroll
-        for (int pass = 0; pass < (2 * NBP + 15) / 16; ++pass) {
-            const int fld = 16 * pass + (lane & 15), g = lane >> 4;
-            const int b = fld < NBP ? fld : fld - NBP;
-            if (fld < 2 * NBP && b < nb) {
-                const bool is_min = fld < NBP;
-                int cur = -1;
-                unsigned acc = is_min ? 0xffffffffu : 0u;
-                for (int i = 0; i < 16; ++i) {
-                    const int src = 16 * g + i;
-                    const int key = s_tslot[wv][src];
-                    const unsigned v = tk[fld * 130 + src];
-                    if (key != cur) {
-                        if (cur >= 0) { if (is_min) atomicMin(&s_mn[cur][b], acc); else atomicMax(&s_mx[cur][b], acc); }
-                        cur = key; acc = is_min ? 0xffffffffu : 0u;
-                    }
-                    if (key >= 0) acc = is_min ? min(acc, v) : max(acc, v);
-                }
-                if (cur >= 0) { if (is_min) atomicMin(&s_mn[cur][b], acc); else atomicMax(&s_mx[cur][b], acc); }
-            }
-        }
-        zonal_wave_sync();
     }
+    close_run();
     __syncthreads();
-    for (int i = tid; i < Z_SLOTS * nb; i += Z_NT) {
+    for (int i = tid; i < Z_SLOTS * nb; i += NT) {
         const int slot = i / nb, b = i - slot * nb;
         const int l = s_key[slot];
         if (l < 0) continue;
@@ -316,7 +264,7 @@ int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int 
     hipLaunchKernelGGL(zonal_init_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx, (long long)n_labels, bl.n);
     const int tiles = cdiv(W, Z_TILE) * cdiv(H, Z_TILE);
 #define LAUNCH_ZONAL(NBPV)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_kernel<NBPV>), dim3(tiles), dim3(Z_NT), 0, ctx->stream, raw, labels, H, W, C, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_kernel<NBPV>), dim3(tiles), dim3(16 * NBPV), 0, ctx->stream, raw, labels, H, W, C, \
                        bl, n_labels, start_label, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx)
     if (bl.n <= 4) LAUNCH_ZONAL(4);
     else if (bl.n <= 8) LAUNCH_ZONAL(8);
