@@ -81,6 +81,15 @@ constexpr int FP_NT = 256;
 // K0a: per-band min/max of each problem window.  A row of a band-interleaved window is a flat run of
 // w*C floats; lanes read it as coalesced float4 (C % 4 == 0) or dwords, and the thread count in use is a
 // multiple of the band period so that every thread owns a fixed band (group).  grid = (blocks, nprob).
+// Global atomics that land on a handful of addresses cost several ns EACH, device-wide (measured: 35k atomicMax on one
+// word add 180 us to a 240-us pass).  A running min / max only needs the atomic when it improves the published value.
+__device__ __forceinline__ void lazy_atomic_min(unsigned *a, unsigned v) {
+    if (v < __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(a, v);
+}
+__device__ __forceinline__ void lazy_atomic_max(unsigned *a, unsigned v) {
+    if (v > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, v);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restrict__ src, int Ws, int C,
                                                             const SrcWindow *__restrict__ wins,
@@ -102,17 +111,32 @@ __global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restr
         const long long row_vecs = (long long)wdw.w * period;
         for (int y = blockIdx.x; y < wdw.h; y += gridDim.x) {
             const float *row = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0) * C;
-            for (long long e = tid; e < row_vecs; e += active) {
-                float v[VEC];
-                if (VEC == 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(row + 4 * e);
-                    v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
-                } else v[0] = row[e];
+            // four loads in flight per lane (a lane keeps its bands: the stride `active` is a multiple of the period)
+            constexpr int MU = 4;
+            for (long long e0 = tid; e0 < row_vecs; e0 += (long long)MU * active) {
+                float v[MU][VEC];
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    bad |= !(fabsf(v[q]) <= 3.4028234e38f);
-                    lo[q] = fminf(lo[q], v[q]);
-                    hi[q] = fmaxf(hi[q], v[q]);
+                for (int u = 0; u < MU; ++u) {
+                    const long long e = e0 + (long long)u * active;
+                    if (e < row_vecs) {
+                        if (VEC == 4) {
+                            const float4 t = *reinterpret_cast<const float4 *>(row + 4 * e);
+                            v[u][0] = t.x; v[u][1 % VEC] = t.y; v[u][2 % VEC] = t.z; v[u][3 % VEC] = t.w;
+                        } else v[u][0] = row[e];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) v[u][q] = lo[q];   // neutral: already inside [lo, hi] or +inf (ignored below)
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MU; ++u) {
+                    const bool live = e0 + (long long)u * active < row_vecs;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        if (live) bad |= !(fabsf(v[u][q]) <= 3.4028234e38f);
+                        lo[q] = fminf(lo[q], v[u][q]);
+                        if (live) hi[q] = fmaxf(hi[q], v[u][q]);
+                    }
                 }
             }
         }
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(FP_NT) void band_minmax_kernel(const float *__restr
                 atomicMin(&s_mn[band0 + q], f2key(lo[q]));
                 atomicMax(&s_mx[band0 + q], f2key(hi[q]));
             }
-        if (bad) atomicOr(&nonfinite[p], 1);
+        if (bad && __hip_atomic_load(&nonfinite[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&nonfinite[p], 1);
     }
     __syncthreads();
     if (tid < C) {
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     // wave max -> one atomic per wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(maxabs_bits, __float_as_uint(local_max));
+    if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits, __float_as_uint(local_max));
 }
 
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
@@ -404,23 +428,38 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const SlicProblem *__r
     const long long h0 = head < npix ? head : npix;
     const long long nvec = (npix - h0) / 16;
     const uint4 *mv = reinterpret_cast<const uint4 *>(m + h0);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const uint4 t = mv[i];
+    auto popnz = [](const uint4 &t) {
+        int n = 0;
         const unsigned wds[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned nz = wds[q] | (wds[q] >> 4);
             nz |= nz >> 2; nz |= nz >> 1;
-            c += __popc(nz & 0x01010101u);
+            n += __popc(nz & 0x01010101u);
         }
+        return n;
+    };
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four loads in flight
+        const uint4 t0 = mv[i], t1 = mv[i + stride], t2 = mv[i + 2 * stride], t3 = mv[i + 3 * stride];
+        c += popnz(t0) + popnz(t1) + popnz(t2) + popnz(t3);
     }
+    for (; i < nvec; i += stride) c += popnz(mv[i]);
     if (blockIdx.x == 0) {   // unaligned head and tail bytes
-        for (long long i = threadIdx.x; i < h0; i += blockDim.x) c += m[i] != 0;
-        for (long long i = h0 + nvec * 16 + threadIdx.x; i < npix; i += blockDim.x) c += m[i] != 0;
+        for (long long j = threadIdx.x; j < h0; j += blockDim.x) c += m[j] != 0;
+        for (long long j = h0 + nvec * 16 + threadIdx.x; j < npix; j += blockDim.x) c += m[j] != 0;
     }
+    // one atomic per workgroup: atomics on one word serialise device-wide
+    __shared__ int s_c[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&out[p], c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        if (tot) atomicAdd(&out[p], tot);
+    }
 }
 
 int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
@@ -436,7 +475,7 @@ int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
         OBIA_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * np, ctx->stream));
         long long maxpix = 1;
         for (auto &P : b.probs) { long long n = (long long)P.H * P.W; if (n > maxpix) maxpix = n; }
-        int blocks = cdiv(maxpix, 256 * 16 * 4);
+        int blocks = cdiv(maxpix, 256 * 16 * 32);
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(count_valid_kernel, dim3(blocks, np), dim3(256), 0, ctx->stream, b.d_probs, b.d_mask, d_cnt);
         OBIA_TRY(read_back(ctx, nvalid.data(), d_cnt, sizeof(int) * np));
