@@ -49,10 +49,13 @@ constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
 // write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
-// linked list of the bin that holds its current position.  One thread per centroid.
+// linked list of the bin that holds its current position.
+// G = RQ lanes per centroid: lane q of a group owns qword q of the 128-B (256-B) accumulator record, so the record is
+// read and cleared with one coalesced access per wave; n and the coordinate sums reach the group by shuffle.
+template <int G>
 __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__restrict__ probs,
                                                         const int *__restrict__ cent_prob, int total_cent, int CP,
-                                                        int RQ, int first, const float *__restrict__ seed,
+                                                        int first, const float *__restrict__ seed,
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
                                                         int *__restrict__ next, int *__restrict__ head_other,
@@ -63,51 +66,62 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     // the bin heads are double-buffered: while this sweep fills `head`, the buffer of the NEXT sweep is reset here
     // (saves one memset launch per sweep)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= total_cent) return;
-    const int p = cent_prob[k];
-    if (p < 0) return;
-    const SlicProblem P = probs[p];
-    if (k - P.cent_off >= P.K) return;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = gt / G, q = gt % G;
+    const int lane = threadIdx.x & 63, gl0 = lane - q;       // first lane of the group inside the wave
+    const bool in_range = k < total_cent;
+    const int p = in_range ? cent_prob[k] : -1;
+    SlicProblem P;
+    bool live = p >= 0;
+    if (live) { P = probs[p]; live = (k - P.cent_off) < P.K; }
     const int RS = CENT_REC + CP;
-    float *rec = cent + (size_t)k * RS;
-    float cy, cx;
+    float *rec = cent + (size_t)(live ? k : 0) * RS;
+    float cy = 0.0f, cx = 0.0f;
     bool moved = false;
-    const float old_cy = rec[0], old_cx = rec[1];
+    const float old_cy = live ? rec[0] : 0.0f, old_cx = live ? rec[1] : 0.0f;
     if (first) {
-        cy = seed[2 * (size_t)k];
-        cx = seed[2 * (size_t)k + 1];
-        for (int c = 0; c < CP; ++c) rec[CENT_REC + c] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
+        if (live) {
+            cy = seed[2 * (size_t)k];
+            cx = seed[2 * (size_t)k + 1];
+            if (q < CP) rec[CENT_REC + q] = 0.0f;   // initial centroid colour is zero (slic_superpixels.py:298-300)
+        }
         moved = true;
     } else {
-        unsigned long long *a = acc + (size_t)k * RQ;
-        const unsigned long long ny = a[CP];
+        unsigned long long *a = acc + (size_t)(live ? k : 0) * G;
+        const unsigned long long aq = live ? a[q] : 0ull;
+        const float oldc = (live && q < CP) ? rec[CENT_REC + q] : 0.0f;
+        if (live) a[q] = 0ull;
+        // every lane takes part in the shuffles (dead groups carry zeros)
+        const unsigned long long ny = __shfl(aq, gl0 + CP);
+        const unsigned long long sxq = __shfl(aq, gl0 + CP + 1);
         const unsigned n = (unsigned)(ny & 0xffffffffull);
         const float fn = (float)n;
         // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
         cy = (float)(unsigned)(ny >> 32) / fn;
-        cx = (float)(unsigned)a[CP + 1] / fn;
-        for (int c = 0; c < CP; ++c) {
-            const float s = (float)((double)(long long)a[c] * inv_fscale);
-            const float v = s / fn;
-            moved |= __float_as_uint(v) != __float_as_uint(rec[CENT_REC + c]);
-            rec[CENT_REC + c] = v;
-            a[c] = 0;
+        cx = (float)(unsigned)sxq / fn;
+        bool mq = false;
+        if (live && q < CP) {
+            const float sum = (float)((double)(long long)aq * inv_fscale);
+            const float v = sum / fn;
+            mq = __float_as_uint(v) != __float_as_uint(oldc);
+            rec[CENT_REC + q] = v;
         }
-        a[CP] = 0; a[CP + 1] = 0;
-        moved |= __float_as_uint(cy) != __float_as_uint(rec[0]) || __float_as_uint(cx) != __float_as_uint(rec[1]);
+        const unsigned long long mb = __ballot(mq);
+        const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gl0);
+        moved = (mb & gmask) != 0ull;
+        moved |= __float_as_uint(cy) != __float_as_uint(old_cy) || __float_as_uint(cx) != __float_as_uint(old_cx);
     }
+    if (!live || q != 0) return;
     if (bin_stamp && moved && !first && old_cy == old_cy && old_cx == old_cx) {   // the bin it leaves
         int oby = (int)(old_cy / (float)P.sy), obx = (int)(old_cx / (float)P.sx);
         oby = oby < 0 ? 0 : (oby >= P.ncy ? P.ncy - 1 : oby);
         obx = obx < 0 ? 0 : (obx >= P.ncx ? P.ncx - 1 : obx);
         bin_stamp[P.cell_off + oby * P.ncx + obx] = sweep_id;
     }
-    rec[0] = cy; rec[1] = cx;
-    int *irec = reinterpret_cast<int *>(rec);
-    irec[6] = k; irec[7] = 0;
+    float4 *hrec = reinterpret_cast<float4 *>(rec);   // records are 16-byte aligned (RS is a multiple of 4)
     if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
-        irec[2] = 0; irec[3] = 0; irec[4] = 0; irec[5] = 0;
+        hrec[0] = make_float4(cy, cx, 0.0f, 0.0f);
+        hrec[1] = make_float4(0.0f, 0.0f, __int_as_float(k), 0.0f);
         next[k] = -1;
         return;
     }
@@ -116,7 +130,8 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
     float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
     float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
-    irec[2] = (int)fy0; irec[3] = (int)fy1; irec[4] = (int)fx0; irec[5] = (int)fx1;
+    hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
+    hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(k), 0.0f);
     int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
     by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
     bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
@@ -718,9 +733,14 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
             int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
             int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
             ++sweep_no;   // sweep ids start at 1
-            hipLaunchKernelGGL(slic_prep_kernel, dim3(cdiv(b.total_cent, 256)), dim3(256), 0, ctx->stream, b.d_probs,
-                               b.d_cent_prob, b.total_cent, b.CP, RQ, first ? 1 : 0, b.d_seed, b.d_acc, 1.0 / b.fscale,
-                               b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+            if (RQ == 16)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv((long long)b.total_cent * 16, 256)), dim3(256), 0,
+                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, b.d_seed, b.d_acc,
+                                   1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv((long long)b.total_cent * 32, 256)), dim3(256), 0,
+                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, b.d_seed, b.d_acc,
+                                   1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
             b.d_head_cur = head_cur;
             first = false;
             // the update after the very last sweep is never read: skip its accumulation
