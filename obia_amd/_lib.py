@@ -167,3 +167,15 @@ def default_context(device=0):
 
 def np_ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def mask_bytes(mask, device=None):
+    """Device mask as one byte per pixel, any non-zero byte = valid (what every kernel tests).  uint8 and bool tensors
+    are passed through without a copy; other dtypes are compared with zero once."""
+    import torch
+    m = torch.as_tensor(mask, device=device)
+    if m.dtype == torch.bool:
+        m = m.contiguous().view(torch.uint8)
+    elif m.dtype != torch.uint8:
+        m = (m != 0).view(torch.uint8)
+    return m.contiguous()

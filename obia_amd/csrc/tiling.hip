@@ -50,11 +50,17 @@ __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *_
     const TileWin t = wins[blockIdx.y];
     const int wround = ((t.w + 255) / 256) * 256;   // whole waves stay in the loop for the wave-level histogram
     for (int y = blockIdx.x; y < t.h; y += gridDim.x)
-        for (int x0 = 0; x0 < wround; x0 += 256) {
-            const int x = x0 + threadIdx.x;
-            int g = 0;
-            if (x < t.w && !in_corner(t, y, x)) g = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
-            wave_hist_add(inside, g, g > 0);
+        for (int x0 = 0; x0 < wround; x0 += 4 * 256) {   // four loads in flight
+            int g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + 256 * u + threadIdx.x;
+                g[u] = 0;
+                if (x < t.w && !in_corner(t, y, x)) g[u] = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (x0 + 256 * u < wround) wave_hist_add(inside, g[u], g[u] > 0);   // wave-uniform condition
         }
 }
 
@@ -66,21 +72,37 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
                                                         uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask) {
     const TileWin t = wins[blockIdx.y];
     for (int y = blockIdx.x; y < t.h; y += gridDim.x)
-    for (int x = threadIdx.x; x < t.w; x += blockDim.x) {
-        const long long i = (long long)y * t.w + x;
-        const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
-        uint8_t m = inmask ? (inmask[gp] != 0) : 1;
-        if (white) {
-            if (in_corner(t, y, x)) m = 0;
-            else {
-                const int g = G[gp];
-                if (g > 0) {
-                    if (inside[g] == seg_size[g]) { G[gp] = 0; alive[g] = 0; }   // within: dropped
-                    else m = 0;                                                    // overlaps: kept, masked out
-                }
+    for (int x0 = threadIdx.x; x0 < t.w; x0 += 4 * 256) {   // four pixels in flight per lane
+        uint8_t mv[4];
+        int gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = x0 + 256 * u;
+            mv[u] = 0; gv[u] = 0;
+            if (x < t.w) {
+                const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
+                mv[u] = inmask ? (inmask[gp] != 0) : 1;
+                if (white && !in_corner(t, y, x)) gv[u] = G[gp];
             }
         }
-        dmask[t.pix_off + i] = m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = x0 + 256 * u;
+            if (x >= t.w) continue;
+            const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
+            uint8_t m = mv[u];
+            if (white) {
+                if (in_corner(t, y, x)) m = 0;
+                else {
+                    const int g = gv[u];
+                    if (g > 0) {
+                        if (inside[g] == seg_size[g]) { G[gp] = 0; alive[g] = 0; }   // within: dropped
+                        else m = 0;                                                    // overlaps: kept, masked out
+                    }
+                }
+            }
+            dmask[t.pix_off + (long long)y * t.w + x] = m;
+        }
     }
 }
 
@@ -91,61 +113,98 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileWin *__rest
     const TileWin t = wins[blockIdx.y];
     const int wround = ((t.w + 255) / 256) * 256;
     for (int y = blockIdx.x; y < t.h; y += gridDim.x)
-        for (int x0 = 0; x0 < wround; x0 += 256) {
-            const int x = x0 + threadIdx.x;
-            int id = 0;
-            if (x < t.w) {
-                const int l = lab[t.pix_off + (long long)y * t.w + x];
-                if (l > 0) {
-                    id = id_base + l;
-                    G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id;
+        for (int x0 = 0; x0 < wround; x0 += 4 * 256) {   // four loads in flight
+            int id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + 256 * u + threadIdx.x;
+                id[u] = 0;
+                if (x < t.w) {
+                    const int l = lab[t.pix_off + (long long)y * t.w + x];
+                    if (l > 0) id[u] = id_base + l;
                 }
             }
-            wave_hist_add(seg_size, id, id > 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + 256 * u + threadIdx.x;
+                if (id[u] > 0) G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id[u];
+                if (x0 + 256 * u < wround) wave_hist_add(seg_size, id[u], id[u] > 0);   // wave-uniform condition
+            }
         }
 }
 
-// final ids 1..N: exclusive scan over the alive flags of the provisional ids.  Single workgroup (the id table is
-// ~1e6 entries), chunked so that every load is a coalesced 16-byte read.
-__global__ __launch_bounds__(1024) void ids_scan_kernel(const uint8_t *__restrict__ alive, int n_ids, int *__restrict__ newid,
-                                                        long long *__restrict__ total) {
+// final ids 1..N: exclusive scan over the alive flags of the provisional ids (the table has ~1e6 entries).
+// Two launches: per-chunk counts, then every workgroup adds up the counts of the chunks before its own and scans its
+// chunk of 1024 x 16 flags (coalesced 16-byte reads).
+constexpr int IDS_CHUNK = 1024 * 16;
+
+__global__ __launch_bounds__(1024) void ids_count_kernel(const uint8_t *__restrict__ alive, int n_ids, int *__restrict__ partial) {
     __shared__ int s_wave[16];
-    __shared__ int s_run;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_run = 0;
+    const int i0 = blockIdx.x * IDS_CHUNK + tid * 16;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c += (i0 + q < n_ids) ? (alive[i0 + q] != 0) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) s_wave[wv] = c;
     __syncthreads();
-    for (int base = 0; base < n_ids; base += 1024 * 16) {
-        const int i0 = base + tid * 16;
-        unsigned char f[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) f[q] = (i0 + q < n_ids) ? alive[i0 + q] : 0;
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c += f[q] != 0;
-        // inclusive scan of c over the wave (shuffle up), then over the 16 waves
-        int inc = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(inc, off);
-            if (lane >= off) inc += v;
-        }
-        if (lane == 63) s_wave[wv] = inc;
-        __syncthreads();
-        int before = s_run;
-        for (int w2 = 0; w2 < wv; ++w2) before += s_wave[w2];
-        int run = before + inc - c;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (i0 + q < n_ids) { if (f[q]) { run += 1; newid[i0 + q] = run; } else newid[i0 + q] = 0; }
-        __syncthreads();
-        if (tid == 1023) s_run = before + inc;
-        __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w2 = 0; w2 < 16; ++w2) t += s_wave[w2];
+        partial[blockIdx.x] = t;
     }
-    if (tid == 0) *total = s_run;
 }
 
-__global__ void ids_apply_kernel(int32_t *__restrict__ G, long long n, const int *__restrict__ newid) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(1024) void ids_scan_kernel(const uint8_t *__restrict__ alive, int n_ids, const int *__restrict__ partial,
+                                                        int *__restrict__ newid, long long *__restrict__ total) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // alive ids in the chunks before this one
+    int pre = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += 1024) pre += partial[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off);
+    if (lane == 0) s_base[wv] = pre;
+    const int i0 = blockIdx.x * IDS_CHUNK + tid * 16;
+    unsigned char f[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f[q] = (i0 + q < n_ids) ? alive[i0 + q] : 0;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c += f[q] != 0;
+    // inclusive scan of c over the wave (shuffle up), then over the 16 waves
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int w2 = 0; w2 < 16; ++w2) { before += s_base[w2]; if (w2 < wv) before += s_wave[w2]; }
+    int run = before + inc - c;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (i0 + q < n_ids) { if (f[q]) { run += 1; newid[i0 + q] = run; } else newid[i0 + q] = 0; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023) *total = before + inc;
+}
+
+// G[i] = newid[G[i]]: four pixels per lane and step (one 16-byte access, four gathers in flight)
+__global__ __launch_bounds__(256) void ids_apply_kernel(int32_t *__restrict__ G, long long n, const int *__restrict__ newid) {
+    const long long n4 = ((reinterpret_cast<uintptr_t>(G) & 15) == 0) ? n / 4 : 0;
+    int4 *G4 = reinterpret_cast<int4 *>(G);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        int4 g = G4[i];
+        g.x = g.x > 0 ? newid[g.x] : 0;
+        g.y = g.y > 0 ? newid[g.y] : 0;
+        g.z = g.z > 0 ? newid[g.z] : 0;
+        g.w = g.w > 0 ? newid[g.w] : 0;
+        G4[i] = g;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int g = G[i];
         G[i] = g > 0 ? newid[g] : 0;
     }
@@ -358,8 +417,12 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
 
 // ids 1..N: black survivors first, then white, each in creation order (tiling.py:289-290)
 static int tiler_finalize(obia_ctx *ctx, TileState &S, int64_t *n_segments_out) {
-    hipLaunchKernelGGL(ids_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.alive, S.next_id, S.newid, S.d_total);
-    int g = cdiv((long long)S.H * S.W, 256 * 8);
+    const int nchunks = cdiv(S.next_id, IDS_CHUNK);
+    int *d_partial = ctx->arena.get<int>((size_t)nchunks);
+    if (!d_partial) return OBIA_E_NOMEM;
+    hipLaunchKernelGGL(ids_count_kernel, dim3(nchunks), dim3(1024), 0, ctx->stream, S.alive, S.next_id, d_partial);
+    hipLaunchKernelGGL(ids_scan_kernel, dim3(nchunks), dim3(1024), 0, ctx->stream, S.alive, S.next_id, d_partial, S.newid, S.d_total);
+    int g = cdiv((long long)S.H * S.W, 256 * 16);
     if (g > 65535) g = 65535;
     hipLaunchKernelGGL(ids_apply_kernel, dim3(g), dim3(256), 0, ctx->stream, S.G, (long long)S.H * S.W, S.newid);
     OBIA_HIP_TRY(hipGetLastError());

@@ -121,7 +121,7 @@ class ShardedTiler:
         # ---- halo exchange of image and mask rows (once) ------------------------------------------------------
         if mask_slab is None:
             mask_slab = torch.ones((Hs, W), dtype=torch.uint8, device=self.dev)
-        mask_slab = (mask_slab != 0).to(torch.uint8)
+        mask_slab = _lib.mask_bytes(mask_slab, self.dev)
         ext = torch.empty((self.top + Hs + self.bot, W, slab.shape[2]), dtype=torch.float32, device=self.dev)
         mext = torch.empty((self.top + Hs + self.bot, W), dtype=torch.uint8, device=self.dev)
         ext[self.top:self.top + Hs] = slab

@@ -94,7 +94,7 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
             m = torch.as_tensor(mask, device=img.device)
             if tuple(m.shape) != (H, W):
                 raise ValueError("image and mask should have the same shape.")
-            m = (m != 0).to(torch.uint8).contiguous()
+            m = _lib.mask_bytes(m)
         dev = img.device.index or 0
         c = ctx or _lib.default_context(dev)
         torch.cuda.current_stream(dev).synchronize()

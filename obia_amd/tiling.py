@@ -97,7 +97,7 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
         H, W, C = x.shape
         m = None
         if input_mask is not None:
-            m = (torch.as_tensor(input_mask, device=x.device) != 0).to(torch.uint8).contiguous()
+            m = _lib.mask_bytes(input_mask, x.device)
             if tuple(m.shape) != (H, W):
                 raise ValueError("image and mask should have the same shape.")
         dev = x.device.index or 0
