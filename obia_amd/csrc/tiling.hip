@@ -106,31 +106,62 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
     }
 }
 
-// step 3: write the new segments of the batch into G with their provisional global ids + size histogram
-__global__ __launch_bounds__(256) void tile_scatter_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ lab,
-                                                           int32_t *__restrict__ G, int Wr, int id_base,
-                                                           unsigned *__restrict__ seg_size) {
+// step 3: write the new segments of the batch into G with their provisional global ids + size histogram.
+// Global atomics run at ~2e10 per second device-wide, so the histogram is built per 64x64 block of the window first:
+// a lane walks one column (runs of equal label down the column are counted in a register), run totals go to a 128-slot
+// LDS table keyed by label, and the table is flushed with one global atomic per (block, label).
+constexpr int TS_SLOTS = 128;
+__global__ __launch_bounds__(64) void tile_scatter_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ lab,
+                                                          int32_t *__restrict__ G, int Wr, int id_base,
+                                                          unsigned *__restrict__ seg_size) {
+    __shared__ int s_key[TS_SLOTS];
+    __shared__ unsigned s_cnt[TS_SLOTS];
     const TileWin t = wins[blockIdx.y];
-    const int wround = ((t.w + 255) / 256) * 256;
-    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
-        for (int x0 = 0; x0 < wround; x0 += 4 * 256) {   // four loads in flight
-            int id[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int x = x0 + 256 * u + threadIdx.x;
-                id[u] = 0;
-                if (x < t.w) {
-                    const int l = lab[t.pix_off + (long long)y * t.w + x];
-                    if (l > 0) id[u] = id_base + l;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int x = x0 + 256 * u + threadIdx.x;
-                if (id[u] > 0) G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id[u];
-                if (x0 + 256 * u < wround) wave_hist_add(seg_size, id[u], id[u] > 0);   // wave-uniform condition
-            }
+    const int bw = (t.w + 63) / 64;
+    const int by = blockIdx.x / bw, bx = blockIdx.x % bw;
+    if (by * 64 >= t.h) return;   // whole workgroup
+    const int lane = threadIdx.x;
+    for (int i = lane; i < TS_SLOTS; i += 64) { s_key[i] = 0; s_cnt[i] = 0; }
+    __syncthreads();
+    const int x = bx * 64 + lane;
+    const bool col_ok = x < t.w;
+    const int y_lo = by * 64, y_hi = min(y_lo + 64, t.h);
+    int rid = 0;
+    unsigned rn = 0;
+    auto close_run = [&]() {
+        if (rid <= 0) return;
+        const unsigned h = ((unsigned)rid * 2654435761u) >> 25;
+        int slot = -1;
+#pragma unroll 1
+        for (int probe = 0; probe < TS_SLOTS; ++probe) {
+            const int sidx = (h + probe) & (TS_SLOTS - 1);
+            const int old = atomicCAS(&s_key[sidx], 0, rid);
+            if (old == 0 || old == rid) { slot = sidx; break; }
         }
+        if (slot >= 0) atomicAdd(&s_cnt[slot], rn);
+        else atomicAdd(&seg_size[rid], rn);          // table full: straight to global memory
+    };
+#pragma unroll 1
+    for (int y0 = y_lo; y0 < y_hi; y0 += 8) {       // eight rows in flight
+        int l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int y = y0 + j;
+            l[j] = (col_ok && y < y_hi) ? lab[t.pix_off + (long long)y * t.w + x] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int y = y0 + j;
+            const int id = l[j] > 0 ? id_base + l[j] : 0;
+            if (id > 0) G[(long long)(t.y0 + y) * Wr + t.x0 + x] = id;
+            if (id != rid) { close_run(); rid = id; rn = 0; }
+            rn += 1;
+        }
+    }
+    close_run();
+    __syncthreads();
+    for (int i = lane; i < TS_SLOTS; i += 64)
+        if (s_key[i] > 0 && s_cnt[i]) atomicAdd(&seg_size[s_key[i]], s_cnt[i]);
 }
 
 // final ids 1..N: exclusive scan over the alive flags of the provisional ids (the table has ~1e6 entries).
@@ -311,7 +342,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     }
     if (S.next_id + n_new > S.id_cap) { set_error("segment id capacity exceeded (%d + %d > %d)", S.next_id, n_new, S.id_cap); return OBIA_E_NOMEM; }
     if (n_new > 0) {
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, d_final, S.G, S.W,
+        int sblocks = 1;
+        for (auto &t : wins) sblocks = std::max(sblocks, cdiv(t.w, 64) * cdiv(t.h, 64));
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(sblocks, np), dim3(64), 0, ctx->stream, d_wins, d_final, S.G, S.W,
                            S.next_id - 1, S.seg_size);
         OBIA_HIP_TRY(hipMemsetAsync(S.alive + S.next_id, 1, (size_t)n_new, ctx->stream));
         S.next_id += n_new;
