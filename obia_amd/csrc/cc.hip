@@ -109,10 +109,14 @@ __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restric
         s_lab[i] = (y < P.H && x < P.W) ? lab[P.pix_off + (long long)y * P.W + x] : mask_label;
     }
     __syncthreads();
+    // a wave holds one tile row (CT_W == 64): the parent of a pixel is the head of its horizontal run, found with one
+    // ballot (the highest run start at or below the lane), so the chains that lfind() walks only hop between run heads
     for (int i = tid; i < CT_N; i += 256) {
         const int lx = i % CT_W;
         const int l = s_lab[i];
-        s_par[i] = (unsigned short)((l != mask_label && lx > 0 && s_lab[i - 1] == l) ? i - 1 : i);
+        const bool start = (l == mask_label) || lx == 0 || s_lab[i - 1] != l;
+        const unsigned long long starts = __ballot(start) & (~0ull >> (63 - lx));
+        s_par[i] = (unsigned short)(i - lx + (63 - __clzll((long long)starts)));
     }
     __syncthreads();
     // 2. vertical contacts (only the first pixel of a horizontal contact issues the union)
