@@ -161,7 +161,14 @@ __global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restric
         const int l = lab[g];
         if (l == mask_label) continue;
         const long long gn = g - (long long)dy * W - dx;
-        if (lab[gn] == l) unite(parent, (int)g, (int)gn);
+        if (lab[gn] != l) continue;
+        // only the first pixel of a contact run issues the union (the previous pixel along the seam, if it carries the
+        // same label on both sides, already links the same two components)
+        const long long gp = dy ? g - 1 : g - W, gnp = dy ? gn - 1 : gn - W;
+        // (only when that pixel lies in the same tile: its link to this pixel is then already inside the tile)
+        const bool has_prev = dy ? (x % CT_W != 0) : (y % CT_H != 0);
+        if (has_prev && lab[gp] == l && lab[gnp] == l) continue;
+        unite(parent, (int)g, (int)gn);
     }
 }
 
