@@ -174,21 +174,45 @@ __global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restric
 
 // flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
 __global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n) {
-    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < n; i0 += (long long)gridDim.x * blockDim.x) {
-        const long long i = i0 + threadIdx.x;
-        int r = -1;
-        if (i < n && parent[i] >= 0) r = find_root(parent, (int)i);
-        bool todo = r >= 0;
-        while (true) {
-            const unsigned long long act = __ballot(todo);
-            if (!act) break;
-            const int leader = __ffsll((long long)act) - 1;
-            const int rr = __shfl(r, leader);
-            const unsigned long long same = __ballot(todo && r == rr);
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[rr], (int)__popcll(same));
-            if (r == rr) todo = false;
+    // four pixels per lane, chased in lockstep: the dependent parent loads of the four chains are in flight together
+    constexpr int FU = 4;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x * FU; i0 < n; i0 += (long long)gridDim.x * blockDim.x * FU) {
+        long long idx[FU];
+        int r[FU];
+        bool open[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            idx[u] = i0 + (long long)u * blockDim.x + threadIdx.x;
+            r[u] = idx[u] < n ? parent[idx[u]] : -1;
+            open[u] = r[u] >= 0 && r[u] != (int)idx[u];     // a pixel that is its own parent is a root already
         }
-        if (i < n && r >= 0) parent[i] = r;   // roots only move to smaller indices, final value is the root
+        for (;;) {
+            int q[FU];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < FU; ++u) if (open[u]) q[u] = ld_agent(&parent[r[u]]);
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+                if (open[u]) {
+                    if (q[u] == r[u]) open[u] = false;
+                    else { r[u] = q[u]; any = true; }
+                }
+            if (!any) break;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            bool todo = r[u] >= 0;
+            while (true) {   // wave-aggregated size: lanes that share a root add once
+                const unsigned long long act = __ballot(todo);
+                if (!act) break;
+                const int leader = __ffsll((long long)act) - 1;
+                const int rr = __shfl(r[u], leader);
+                const unsigned long long same = __ballot(todo && r[u] == rr);
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[rr], (int)__popcll(same));
+                if (r[u] == rr) todo = false;
+            }
+            if (r[u] >= 0) parent[idx[u]] = r[u];   // roots only move to smaller indices, final value is the root
+        }
     }
 }
 
