@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restric
                                                       int *__restrict__ parent, int *__restrict__ size, int mask_label) {
     __shared__ int s_lab[CT_N];
     __shared__ unsigned short s_par[CT_N];
+    __shared__ int s_cnt[CT_N];
     const CcProblem P = probs[blockIdx.y];
     const int tiles_x = (P.W + CT_W - 1) / CT_W;
     const int tile = blockIdx.x;
@@ -111,12 +112,20 @@ __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restric
     __syncthreads();
     // a wave holds one tile row (CT_W == 64): the parent of a pixel is the head of its horizontal run, found with one
     // ballot (the highest run start at or below the lane), so the chains that lfind() walks only hop between run heads
-    for (int i = tid; i < CT_N; i += 256) {
+    int runlen[CT_N / 256];   // pixels of the horizontal run this lane heads (0: not a head, or masked)
+#pragma unroll
+    for (int j = 0; j < CT_N / 256; ++j) {
+        const int i = tid + 256 * j;
         const int lx = i % CT_W;
         const int l = s_lab[i];
         const bool start = (l == mask_label) || lx == 0 || s_lab[i - 1] != l;
-        const unsigned long long starts = __ballot(start) & (~0ull >> (63 - lx));
-        s_par[i] = (unsigned short)(i - lx + (63 - __clzll((long long)starts)));
+        const unsigned long long all = __ballot(start);
+        const unsigned long long below = all & (~0ull >> (63 - lx));
+        s_par[i] = (unsigned short)(i - lx + (63 - __clzll((long long)below)));
+        const unsigned long long above = lx < 63 ? (all >> (lx + 1)) : 0ull;      // run starts to the right of this lane
+        const int end = above ? lx + 1 + __builtin_ctzll(above) : CT_W;
+        runlen[j] = (start && l != mask_label) ? end - lx : 0;
+        s_cnt[i] = 0;
     }
     __syncthreads();
     // 2. vertical contacts (only the first pixel of a horizontal contact issues the union)
@@ -128,19 +137,27 @@ __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restric
         if (!left_same) lunite(s_par, i, i - CT_W);
     }
     __syncthreads();
-    // 3. publish: global index of the local root
-    for (int i = tid; i < CT_N; i += 256) {
+    // 3. pixel count of every tile-local component at its local root (one LDS add per horizontal run), then publish the
+    // global index of the local root.  cc_flatten_kernel sums the local counts per global root: one global atomic per
+    // tile-local component instead of one per wave and root.
+    int rloc[CT_N / 256];
+#pragma unroll
+    for (int j = 0; j < CT_N / 256; ++j) {
+        const int i = tid + 256 * j;
+        rloc[j] = s_lab[i] != mask_label ? lfind(s_par, i) : -1;
+        if (runlen[j] > 0) atomicAdd(&s_cnt[rloc[j]], runlen[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CT_N / 256; ++j) {
+        const int i = tid + 256 * j;
         const int ly = i / CT_W, lx = i % CT_W;
         const int y = ty0 + ly, x = tx0 + lx;
         if (y >= P.H || x >= P.W) continue;
         const long long g = P.pix_off + (long long)y * P.W + x;
-        int p = -1;
-        if (s_lab[i] != mask_label) {
-            const int r = lfind(s_par, i);
-            p = (int)(P.pix_off + (long long)(ty0 + r / CT_W) * P.W + tx0 + r % CT_W);
-        }
-        parent[g] = p;
-        size[g] = 0;
+        const int r = rloc[j];
+        parent[g] = r >= 0 ? (int)(P.pix_off + (long long)(ty0 + r / CT_W) * P.W + tx0 + r % CT_W) : -1;
+        size[g] = s_cnt[i];      // non-zero only at local roots
     }
 }
 
@@ -201,17 +218,13 @@ __global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ paren
         }
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
-            bool todo = r[u] >= 0;
-            while (true) {   // wave-aggregated size: lanes that share a root add once
-                const unsigned long long act = __ballot(todo);
-                if (!act) break;
-                const int leader = __ffsll((long long)act) - 1;
-                const int rr = __shfl(r[u], leader);
-                const unsigned long long same = __ballot(todo && r[u] == rr);
-                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[rr], (int)__popcll(same));
-                if (r[u] == rr) todo = false;
-            }
-            if (r[u] >= 0) parent[idx[u]] = r[u];   // roots only move to smaller indices, final value is the root
+            if (r[u] < 0) continue;
+            parent[idx[u]] = r[u];   // roots only move to smaller indices, final value is the root
+            // size[] arrives with the pixel count of every tile-local component at its local root: a local root that is
+            // not the global root adds its count to the global root (which keeps its own); entries that are not roots
+            // are not read afterwards
+            const int ls = size[idx[u]];
+            if (ls > 0 && r[u] != (int)idx[u]) atomicAdd(&size[r[u]], ls);
         }
     }
 }
