@@ -17,7 +17,7 @@ namespace obia {
 #endif
 constexpr int Z_TILE = 64, Z_SLOTS = 64, Z_MAXB = 16, Z_ROWS = ZR;
 
-struct BandList { int n; int b[Z_MAXB]; };
+struct BandList { int n; int identity; int b[Z_MAXB]; };   // identity: b[i] == i for every i < n
 
 __device__ __forceinline__ unsigned zkey(float f) {
     unsigned b = __float_as_uint(f);
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
     const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
     const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
     const int x = tx0 + tid / LPP, q = tid % LPP;       // column, band quad
-    const bool vec = (C % 4 == 0) && (nb == C);         // all bands in order: one float4 per lane and row
+    const bool vec = (C % 4 == 0) && (nb == C) && bl.identity;   // all bands in order: one float4 per lane and row
     const bool col_ok = x < W;
     int bsel[4];
 #pragma unroll
@@ -252,6 +252,8 @@ int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int 
         }
     }
     for (int i = bl.n; i < Z_MAXB; ++i) bl.b[i] = 0;
+    bl.identity = 1;
+    for (int i = 0; i < bl.n; ++i) if (bl.b[i] != i) bl.identity = 0;
     if (n_labels == 0) return OBIA_OK;
     Arena &A = ctx->arena;
     const size_t nl = (size_t)n_labels, nlb = nl * bl.n;

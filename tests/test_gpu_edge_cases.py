@@ -137,3 +137,28 @@ def test_fixed_point_tile_cache_skips_work_and_keeps_labels(masked, max_iter):
     px_full = t_full["assign_px"] + t_full["prepass_px"]
     px_fast = t_fast["assign_px"] + t_fast["prepass_px"]
     assert px_fast < 0.9 * px_full, (px_fast, px_full)
+
+
+@pytest.mark.parametrize("C,bands", [(5, [4, 0, 2]), (9, [8, 0, 7, 3, 5]), (13, [12, 1, 0, 11, 6, 5, 4, 9, 2]),
+                                     (16, list(range(15, -1, -1))), (8, [3]), (4, None)])
+@pytest.mark.parametrize("block", [4, 23])
+def test_zonal_band_subsets_nans_and_crowded_tiles(oracle, C, bands, block):
+    """Band lists that are re-ordered subsets (lanes own band quads of the LIST, not of the raster), NaN pixels per
+    band, and -- with 4x4-pixel segments -- 256 labels per 64x64 block, four times the slots of the LDS table, so most
+    runs take the overflow path straight to global memory.  Ragged raster (not a multiple of 64)."""
+    from obia_amd.statistics import zonal_stats
+    rs = np.random.RandomState(C * 10 + block)
+    H, W = 150, 203
+    raw = (rs.uniform(-50, 4000, (H, W, C))).astype(np.float32)
+    raw[rs.rand(H, W, C) < 0.01] = np.nan
+    yy, xx = np.mgrid[0:H, 0:W]
+    lab = ((yy // block) * ((W + block - 1) // block) + xx // block + 1).astype(np.int32)
+    lab[rs.rand(H, W) < 0.02] = 0                      # unlabelled pixels are ignored
+    st = zonal_stats(raw, lab, bands=bands)
+    sub = raw if bands is None else raw[:, :, bands]
+    chk = oracle.zonal_stats_numpy(sub, lab)
+    assert np.array_equal(st["count"], chk["count"])
+    np.testing.assert_allclose(st["mean"], chk["mean"], rtol=1e-5, equal_nan=True)
+    np.testing.assert_allclose(st["variance"], chk["variance"], rtol=1e-5, atol=1e-6 * 4050.0 ** 2, equal_nan=True)
+    np.testing.assert_array_equal(st["min"], chk["min"].astype(np.float32))
+    np.testing.assert_array_equal(st["max"], chk["max"].astype(np.float32))
