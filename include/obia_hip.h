@@ -117,6 +117,19 @@ int obia_zonal_stats_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_t 
                              const int32_t *bands, int n_bands, int n_labels, int start_label,
                              int64_t *count_out, double *mean_out, double *var_out, float *min_out, float *max_out);
 
+/* ---- B2 (next row f2): skewness and kurtosis per (label, band) ---------------------------------------------------
+ * Completes calculate_spectral_stats (segment_statistics.py:173-175: scipy.stats.skew / kurtosis with their defaults,
+ * bias=True, fisher=True; NaN for nearly constant data as scipy >= 1.9 does, with float32 eps).  Second pass over
+ * (labels, raw) with the per-label means as pivots (central power sums in float64).
+ *   _dev : mean_dev = the mean table of obia_zonal_stats_f32_dev [n_labels*n_bands]; outputs on the device
+ *   host : runs both passes itself; outputs [n_labels*n_bands] float64 on the host                              */
+int obia_zonal_moments_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_t *labels_hw, int H, int W, int C,
+                               const int32_t *bands, int n_bands, int n_labels, int start_label,
+                               const double *mean_dev, double *skew_out, double *kurt_out);
+int obia_zonal_moments_f32(obia_ctx *ctx, const float *raw_hwc, const int32_t *labels_hw, int H, int W, int C,
+                           const int32_t *bands, int n_bands, int n_labels, int start_label,
+                           double *skew_out, double *kurt_out);
+
 /* ---- B1': quickshift (the alternate method of create_segments, segment_boundaries.py:48-49) ------------------
  * Replaces `segments = quickshift(img_to_segment, **kwargs)`: skimage _quickshift.py:59-74 + _quickshift_cy.pyx.
  * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64

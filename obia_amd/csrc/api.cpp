@@ -217,4 +217,53 @@ int obia_zonal_stats_f32(obia_ctx *ctx, const float *raw, const int32_t *labels,
     return rc;
 }
 
+int obia_zonal_moments_f32_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                               const int32_t *bands, int n_bands, int n_labels, int start_label, const double *mean_dev,
+                               double *skew_out, double *kurt_out) {
+    OBIA_TRY(check_ctx(ctx));
+    if (!raw || !labels || !mean_dev || !skew_out || !kurt_out) { set_error("null pointer argument"); return OBIA_E_INVALID; }
+    ctx->arena.reset();
+    begin_timing(ctx);
+    OBIA_TRY(zonal_moments_dev(ctx, raw, labels, H, W, C, bands, n_bands, n_labels, start_label, mean_dev, skew_out, kurt_out));
+    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    resolve_timing(ctx);
+    return OBIA_OK;
+}
+
+int obia_zonal_moments_f32(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                           const int32_t *bands, int n_bands, int n_labels, int start_label, double *skew_out,
+                           double *kurt_out) {
+    OBIA_TRY(check_ctx(ctx));
+    if (!raw || !labels || !skew_out || !kurt_out || H <= 0 || W <= 0 || C <= 0 || n_labels < 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    const size_t npix = (size_t)H * W;
+    const int nb = bands ? n_bands : C;
+    if (nb < 1 || nb > 16) { set_error("n_bands %d out of range (1..16)", nb); return OBIA_E_UNSUPPORTED; }
+    const size_t nl = (size_t)(n_labels > 0 ? n_labels : 1), nlb = nl * nb;
+    float *d_raw = nullptr; int32_t *d_lab = nullptr;
+    char *d_out = nullptr;
+    const size_t out_bytes = nl * 8 + nlb * (8 + 8 + 4 + 4 + 8 + 8);
+    int rc = OBIA_OK;
+    if (hipMalloc(&d_raw, npix * C * sizeof(float)) != hipSuccess || hipMalloc(&d_lab, npix * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&d_out, out_bytes) != hipSuccess) {
+        set_error("device allocation for host-pointer call failed");
+        rc = OBIA_E_NOMEM;
+    }
+    int64_t *d_cnt = (int64_t *)d_out;
+    double *d_mean = (double *)(d_out + nl * 8), *d_var = d_mean + nlb, *d_skew = d_var + nlb, *d_kurt = d_skew + nlb;
+    float *d_mn = (float *)(d_kurt + nlb), *d_mx = d_mn + nlb;
+    if (rc == OBIA_OK && hipMemcpyAsync(d_raw, raw, npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK && hipMemcpyAsync(d_lab, labels, npix * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
+    if (rc == OBIA_OK) rc = obia_zonal_stats_f32_dev(ctx, d_raw, d_lab, H, W, C, bands, n_bands, n_labels, start_label, d_cnt, d_mean, d_var, d_mn, d_mx);
+    if (rc == OBIA_OK) rc = obia_zonal_moments_f32_dev(ctx, d_raw, d_lab, H, W, C, bands, n_bands, n_labels, start_label, d_mean, d_skew, d_kurt);
+    if (rc == OBIA_OK && n_labels > 0) {
+        bool ok = hipMemcpyAsync(skew_out, d_skew, nlb * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(kurt_out, d_kurt, nlb * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        if (!ok) rc = OBIA_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == OBIA_E_HIP) set_error("host<->device copy failed in obia_zonal_moments_f32");
+    (void)hipFree(d_raw); (void)hipFree(d_lab); (void)hipFree(d_out);
+    return rc;
+}
+
 }  // extern "C"

@@ -98,5 +98,8 @@ int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int
 int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
                     const int32_t *bands_host, int n_bands, int n_labels, int start_label,
                     int64_t *count, double *mean, double *var, float *mn, float *mx);
+int zonal_moments_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                      const int32_t *bands_host, int n_bands, int n_labels, int start_label, const double *mean,
+                      double *skew, double *kurt);
 
 }  // namespace obia

@@ -233,6 +233,209 @@ __global__ void zonal_finalize_kernel(const unsigned *__restrict__ g_cnt, const 
     }
 }
 
+// ---- higher moments: skewness and kurtosis per (label, band) -------------------------------------------
+// scipy.stats.skew / kurtosis with their defaults (bias=True, fisher=True; segment_statistics.py:173-175):
+//   m_k = mean((x - mean)^k),  skewness = m3 / m2^1.5,  kurtosis = m4 / m2^2 - 3,
+//   NaN where m2 <= (eps * mean)^2 (scipy >= 1.9: "nearly constant" data), eps = float32 epsilon (the raster dtype).
+// Second pass of the same shape as zonal_kernel: the per-label means of the first pass are the pivots, so the power
+// sums are CENTRAL (no cancellation); a lane loads the four means of its band quad once per run.
+template <int NBP>
+__global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_moments_kernel(
+    const float *__restrict__ raw, const int32_t *__restrict__ labels, int H, int W, int C, BandList bl, int n_labels,
+    int start_label, const double *__restrict__ mean, unsigned *__restrict__ g_n, double *__restrict__ g_s2,
+    double *__restrict__ g_s3, double *__restrict__ g_s4) {
+    constexpr int LPP = NBP / 4, NT = 64 * LPP;
+    __shared__ int s_key[Z_SLOTS];
+    __shared__ unsigned s_n[Z_SLOTS][NBP];
+    __shared__ double s_s2[Z_SLOTS][NBP], s_s3[Z_SLOTS][NBP], s_s4[Z_SLOTS][NBP];
+    const int tid = threadIdx.x;
+    const int nb = bl.n;
+    for (int i = tid; i < Z_SLOTS; i += NT) s_key[i] = -1;
+    for (int i = tid; i < Z_SLOTS * NBP; i += NT) {
+        (&s_n[0][0])[i] = 0u; (&s_s2[0][0])[i] = 0.0; (&s_s3[0][0])[i] = 0.0; (&s_s4[0][0])[i] = 0.0;
+    }
+    __syncthreads();
+    const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
+    const int x = tx0 + tid / LPP, q = tid % LPP;
+    const bool vec = (C % 4 == 0) && (nb == C) && bl.identity;
+    const bool col_ok = x < W;
+    int bsel[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bsel[b] = (q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b];
+    const int nbq = min(4, max(0, nb - 4 * q));
+
+    int rl = -1;
+    unsigned rn[4];
+    double mu[4], r2[4], r3[4], r4[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { rn[b] = 0; mu[b] = 0.0; r2[b] = 0.0; r3[b] = 0.0; r4[b] = 0.0; }
+    auto close_run = [&]() {
+        if (rl < 0) return;
+        const unsigned h = ((unsigned)rl * 2654435761u) >> 26;
+        int slot = -1;
+#pragma unroll 1
+        for (int probe = 0; probe < Z_SLOTS; ++probe) {
+            const int sidx = (h + probe) & (Z_SLOTS - 1);
+            const int old = atomicCAS(&s_key[sidx], -1, rl);
+            if (old == -1 || old == rl) { slot = sidx; break; }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b >= nbq || rn[b] == 0) continue;
+            if (slot >= 0) {
+                atomicAdd(&s_n[slot][4 * q + b], rn[b]);
+                atomicAdd(&s_s2[slot][4 * q + b], r2[b]);
+                atomicAdd(&s_s3[slot][4 * q + b], r3[b]);
+                atomicAdd(&s_s4[slot][4 * q + b], r4[b]);
+            } else {
+                const size_t o = (size_t)rl * nb + 4 * q + b;
+                atomicAdd(&g_n[o], rn[b]);
+                unsafeAtomicAdd(&g_s2[o], r2[b]);
+                unsafeAtomicAdd(&g_s3[o], r3[b]);
+                unsafeAtomicAdd(&g_s4[o], r4[b]);
+            }
+        }
+    };
+    int lab[2][Z_ROWS];
+    float4 val[2][Z_ROWS];
+    auto fetch = [&](int buf, int y0) {
+#pragma unroll
+        for (int j = 0; j < Z_ROWS; ++j) {
+            const int y = y0 + j;
+            int l = -1;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (col_ok && y < H) {
+                const long long pix = (long long)y * W + x;
+                l = labels[pix] - start_label;
+                if (l < 0 || l >= n_labels) l = -1;
+                if (l >= 0 && nbq > 0) {
+                    const float *px = raw + pix * C;
+                    if (vec) v = reinterpret_cast<const float4 *>(px)[q];
+                    else {
+                        v.x = px[bsel[0]];
+                        if (nbq > 1) v.y = px[bsel[1]];
+                        if (nbq > 2) v.z = px[bsel[2]];
+                        if (nbq > 3) v.w = px[bsel[3]];
+                    }
+                }
+            }
+            lab[buf][j] = l; val[buf][j] = v;
+        }
+    };
+    const int y_end = min(ty0 + Z_TILE, H);
+    fetch(0, ty0);
+#pragma unroll 1
+    for (int g = 0; g < Z_TILE / Z_ROWS; g += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int y0 = ty0 + (g + half) * Z_ROWS;
+            if (y0 >= y_end) break;
+            fetch(half ^ 1, y0 + Z_ROWS);
+#pragma unroll
+            for (int j = 0; j < Z_ROWS; ++j) {
+                const int l = (y0 + j < y_end) ? lab[half][j] : -1;
+                if (l != rl) {
+                    close_run();
+                    rl = l;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        rn[b] = 0; r2[b] = 0.0; r3[b] = 0.0; r4[b] = 0.0;
+                        mu[b] = (l >= 0 && b < nbq) ? mean[(size_t)l * nb + 4 * q + b] : 0.0;
+                    }
+                }
+                if (l < 0) continue;
+                const float v[4] = {val[half][j].x, val[half][j].y, val[half][j].z, val[half][j].w};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b >= nbq || !(v[b] == v[b])) continue;   // NaN pixels are dropped per band
+                    const double d = (double)v[b] - mu[b];
+                    const double d2 = d * d;
+                    rn[b] += 1; r2[b] += d2; r3[b] += d2 * d; r4[b] += d2 * d2;
+                }
+            }
+        }
+    }
+    close_run();
+    __syncthreads();
+    for (int i = tid; i < Z_SLOTS * nb; i += NT) {
+        const int slot = i / nb, b = i - slot * nb;
+        const int l = s_key[slot];
+        if (l < 0 || s_n[slot][b] == 0) continue;
+        const size_t o = (size_t)l * nb + b;
+        atomicAdd(&g_n[o], s_n[slot][b]);
+        unsafeAtomicAdd(&g_s2[o], s_s2[slot][b]);
+        unsafeAtomicAdd(&g_s3[o], s_s3[slot][b]);
+        unsafeAtomicAdd(&g_s4[o], s_s4[slot][b]);
+    }
+}
+
+__global__ void zonal_moments_finalize_kernel(const unsigned *__restrict__ g_n, const double *__restrict__ g_s2,
+                                              const double *__restrict__ g_s3, const double *__restrict__ g_s4,
+                                              const double *__restrict__ mean, long long n, double *__restrict__ skew,
+                                              double *__restrict__ kurt) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned c = g_n[i];
+        double sk = NAN, ku = NAN;
+        if (c > 0) {
+            const double m2 = g_s2[i] / (double)c, m3 = g_s3[i] / (double)c, m4 = g_s4[i] / (double)c;
+            const double t = 1.1920928955078125e-07 * mean[i];      // float32 eps * mean
+            if (!(m2 <= t * t)) {
+                sk = m3 / (m2 * sqrt(m2));
+                ku = m4 / (m2 * m2) - 3.0;
+            }
+        }
+        skew[i] = sk; kurt[i] = ku;
+    }
+}
+
+int zonal_moments_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
+                      const int32_t *bands_host, int n_bands, int n_labels, int start_label, const double *mean,
+                      double *skew, double *kurt) {
+    ScopedSpan span(ctx, T_ZONAL);
+    if (H <= 0 || W <= 0 || C <= 0 || n_labels < 0) { set_error("bad zonal_moments shape"); return OBIA_E_INVALID; }
+    BandList bl;
+    if (bands_host == nullptr) {
+        if (C > Z_MAXB) { set_error("more than %d bands not supported", Z_MAXB); return OBIA_E_UNSUPPORTED; }
+        bl.n = C;
+        for (int i = 0; i < C; ++i) bl.b[i] = i;
+    } else {
+        if (n_bands < 1 || n_bands > Z_MAXB) { set_error("n_bands %d out of range (1..%d)", n_bands, Z_MAXB); return OBIA_E_UNSUPPORTED; }
+        bl.n = n_bands;
+        for (int i = 0; i < n_bands; ++i) {
+            if (bands_host[i] < 0 || bands_host[i] >= C) { set_error("band index %d out of range (0..%d)", bands_host[i], C - 1); return OBIA_E_INVALID; }
+            bl.b[i] = bands_host[i];
+        }
+    }
+    for (int i = bl.n; i < Z_MAXB; ++i) bl.b[i] = 0;
+    bl.identity = 1;
+    for (int i = 0; i < bl.n; ++i) if (bl.b[i] != i) bl.identity = 0;
+    if (n_labels == 0) return OBIA_OK;
+    Arena &A = ctx->arena;
+    const size_t nlb = (size_t)n_labels * bl.n;
+    unsigned *g_n = A.get<unsigned>(nlb);
+    double *g_s2 = A.get<double>(nlb), *g_s3 = A.get<double>(nlb), *g_s4 = A.get<double>(nlb);
+    if (!g_n || !g_s2 || !g_s3 || !g_s4) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(g_n, 0, sizeof(unsigned) * nlb, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(g_s2, 0, sizeof(double) * nlb, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(g_s3, 0, sizeof(double) * nlb, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(g_s4, 0, sizeof(double) * nlb, ctx->stream));
+    const int tiles = cdiv(W, Z_TILE) * cdiv(H, Z_TILE);
+#define LAUNCH_ZM(NBPV)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_moments_kernel<NBPV>), dim3(tiles), dim3(16 * NBPV), 0, ctx->stream, raw, \
+                       labels, H, W, C, bl, n_labels, start_label, mean, g_n, g_s2, g_s3, g_s4)
+    if (bl.n <= 4) LAUNCH_ZM(4);
+    else if (bl.n <= 8) LAUNCH_ZM(8);
+    else LAUNCH_ZM(16);
+#undef LAUNCH_ZM
+    int ib = cdiv((long long)nlb, 256);
+    if (ib > 4096) ib = 4096;
+    hipLaunchKernelGGL(zonal_moments_finalize_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_n, g_s2, g_s3, g_s4, mean,
+                       (long long)nlb, skew, kurt);
+    OBIA_HIP_TRY(hipGetLastError());
+    return OBIA_OK;
+}
+
 int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int H, int W, int C,
                     const int32_t *bands_host, int n_bands, int n_labels, int start_label, int64_t *count,
                     double *mean, double *var, float *mn, float *mx) {

@@ -3,7 +3,8 @@
 Mirrors ``obia.segmentation.segment_statistics.create_objects`` / ``calculate_spectral_stats`` /
 ``_create_empty_stats_columns`` (segment_statistics.py:392-511, :113-176, :12-110) for the statistics on
 the hot path: mean, variance (ddof 0), min, max per band per segment, batched over all segments in one
-GPU pass (libobia_hip.so: obia_zonal_stats_f32).
+GPU pass (libobia_hip.so: obia_zonal_stats_f32), plus skewness / kurtosis from a second pass
+(obia_zonal_moments_f32).
 """
 import ctypes
 import warnings
@@ -22,7 +23,7 @@ def _is_torch(x):
     return torch is not None and isinstance(x, torch.Tensor)
 
 
-def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None):
+def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None, moments=False):
     """Per-label statistics of ``raw`` (H,W,C) under the label raster ``labels`` (H,W).
 
     Returns a dict: ``count`` (N,), ``mean``/``variance`` (N,B) float64, ``min``/``max`` (N,B) float32, with
@@ -30,6 +31,10 @@ def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None)
     [start_label, start_label+N) -- e.g. the -1 / 0 of masked pixels -- are ignored; NaN pixels are dropped
     per band; empty segments give NaN (segment_statistics.py:145-162).  NumPy in -> NumPy out; CUDA
     tensors in -> CUDA tensors out.
+
+    ``moments=True`` adds ``skewness`` and ``kurtosis`` (N,B) float64: scipy.stats.skew / kurtosis with their defaults
+    (segment_statistics.py:173-175), computed by a second pass with the per-label means as pivots
+    (obia_zonal_moments_f32_dev).
     """
     lib = _lib.load()
     if _is_torch(raw):
@@ -60,7 +65,15 @@ def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None)
         _lib.check(lib.obia_zonal_stats_f32_dev(c.handle, r.data_ptr(), lab.data_ptr(), H, W, C, _lib.np_ptr(barr), B,
                                                 n_labels, int(start_label), cnt.data_ptr(), mean.data_ptr(),
                                                 var.data_ptr(), mn.data_ptr(), mx.data_ptr()))
-        return {"count": cnt, "mean": mean, "variance": var, "min": mn, "max": mx, "bands": bl}
+        out = {"count": cnt, "mean": mean, "variance": var, "min": mn, "max": mx, "bands": bl}
+        if moments:
+            skew = torch.full_like(mean, float("nan"))
+            kurt = torch.full_like(mean, float("nan"))
+            _lib.check(lib.obia_zonal_moments_f32_dev(c.handle, r.data_ptr(), lab.data_ptr(), H, W, C, _lib.np_ptr(barr), B,
+                                                      n_labels, int(start_label), mean.data_ptr(), skew.data_ptr(),
+                                                      kurt.data_ptr()))
+            out["skewness"], out["kurtosis"] = skew, kurt
+        return out
     r = np.ascontiguousarray(raw, dtype=np.float32)
     if r.ndim != 3:
         raise ValueError("raw must be (H,W,C)")
@@ -86,7 +99,14 @@ def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None)
     _lib.check(lib.obia_zonal_stats_f32(c.handle, _lib.np_ptr(r), _lib.np_ptr(lab), H, W, C, _lib.np_ptr(barr), B, n_labels,
                                         int(start_label), _lib.np_ptr(cnt), _lib.np_ptr(mean), _lib.np_ptr(var),
                                         _lib.np_ptr(mn), _lib.np_ptr(mx)))
-    return {"count": cnt, "mean": mean, "variance": var, "min": mn, "max": mx, "bands": bl}
+    out = {"count": cnt, "mean": mean, "variance": var, "min": mn, "max": mx, "bands": bl}
+    if moments:
+        skew = np.full((n_labels, B), np.nan, np.float64)
+        kurt = np.full((n_labels, B), np.nan, np.float64)
+        _lib.check(lib.obia_zonal_moments_f32(c.handle, _lib.np_ptr(r), _lib.np_ptr(lab), H, W, C, _lib.np_ptr(barr), B,
+                                              n_labels, int(start_label), _lib.np_ptr(skew), _lib.np_ptr(kurt)))
+        out["skewness"], out["kurtosis"] = skew, kurt
+    return out
 
 
 def stats_columns(spectral_bands, textural_bands=(), calc_mean=True, calc_variance=True, calc_min=True, calc_max=True,
@@ -117,8 +137,8 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
     ``segments``: the label raster from create_segments (one 4-connected component per label, so "pixels
     inside polygon p" are "pixels carrying label p").  ``image``: object with ``img_data`` or
     the raw (H,W,C) array.  Returns a pandas DataFrame whose columns follow the reference's order;
-    mean/variance/min/max come from the GPU pass.  Skewness / kurtosis and the GLCM texture columns are the
-    next stages outside this path: requested columns are present and NaN, with a warning.
+    mean/variance/min/max and skewness/kurtosis come from the GPU passes.  The GLCM texture columns are the next
+    stage outside this path: requested texture columns are present and NaN, with a warning.
     """
     import pandas as pd
     if not (calculate_spectral or calculate_textural or calculate_structural or calculate_radiometric):
@@ -133,7 +153,8 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
         spectral_bands = list(range(C))
     tex_bands = list(textural_bands) if (calculate_textural and textural_bands is not None) else (
         list(range(C)) if calculate_textural else [])
-    st = zonal_stats(img_data, segments, bands=spectral_bands, start_label=start_label, ctx=ctx)
+    st = zonal_stats(img_data, segments, bands=spectral_bands, start_label=start_label, ctx=ctx,
+                     moments=bool(calc_skewness or calc_kurtosis))
     if _is_torch(st["count"]):
         st = {k: (v.cpu().numpy() if _is_torch(v) else v) for k, v in st.items()}
     n = st["count"].shape[0]
@@ -144,7 +165,8 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
     pending = []
     for j, b in enumerate(spectral_bands):
         for name, key, on in (("mean", "mean", calc_mean), ("variance", "variance", calc_variance),
-                              ("min", "min", calc_min), ("max", "max", calc_max)):
+                              ("min", "min", calc_min), ("max", "max", calc_max),
+                              ("skewness", "skewness", calc_skewness), ("kurtosis", "kurtosis", calc_kurtosis)):
             if on:
                 data[f"b{b}_{name}"] = st[key][:, j]
     for c in cols:
@@ -152,6 +174,6 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
             data[c] = np.full(n, np.nan)
             pending.append(c)
     if pending:
-        warnings.warn("obia_amd: skewness/kurtosis/texture columns are not computed in this version and are NaN "
+        warnings.warn("obia_amd: GLCM texture columns are not computed in this version and are NaN "
                       f"({len(pending)} columns)", RuntimeWarning, stacklevel=2)
     return pd.DataFrame(data, columns=cols)

@@ -169,7 +169,8 @@ def zonal_stats_numpy(raw, labels, bands=None, start_label=1, n_labels=None):
         n_labels = int(lab.max()) - start_label + 1 if lab.size else 0
     order = np.argsort(lab, kind="stable")
     sl = lab[order]
-    out = {k: np.full((n_labels, len(bands)), np.nan, np.float64) for k in ("mean", "variance", "min", "max")}
+    out = {k: np.full((n_labels, len(bands)), np.nan, np.float64)
+           for k in ("mean", "variance", "min", "max", "skewness", "kurtosis")}
     cnt = np.zeros(n_labels, np.int64)
     flat = raw.reshape(-1, C)
     lo = np.searchsorted(sl, np.arange(start_label, start_label + n_labels), "left")
@@ -188,8 +189,29 @@ def zonal_stats_numpy(raw, labels, bands=None, start_label=1, n_labels=None):
             out["variance"][i, j] = np.var(v)
             out["min"][i, j] = np.min(v)
             out["max"][i, j] = np.max(v)
+            out["skewness"][i, j], out["kurtosis"][i, j] = skew_kurtosis(v)
     out["count"] = cnt
     return out
+
+
+def skew_kurtosis(v):
+    """scipy.stats.skew(v) and scipy.stats.kurtosis(v) with their defaults (bias=True, fisher=True), as
+    calculate_spectral_stats calls them (segment_statistics.py:173-175).  scipy is a dependency of the reference
+    (pyproject.toml: scipy>=1.14.1), not part of /root/reference; this restates its published algorithm
+    (scipy/stats/_stats_py.py, 1.15.3): moments about the mean in the dtype of the data,
+    m_k = mean((v - mean)**k);  skew = m3 / m2**1.5;  kurtosis = m4 / m2**2 - 3;  NaN where
+    m2 <= (eps * mean)**2 (nearly constant data).  Pinned by tests/golden/moments_*.npz (generated by importing scipy)."""
+    v = np.asarray(v)
+    mean = v.mean()
+    d = v - mean
+    m2 = np.mean(d ** 2)
+    m3 = np.mean(d ** 3)
+    m4 = np.mean(d ** 4)
+    eps = np.finfo(m2.dtype).eps
+    with np.errstate(all="ignore"):
+        if m2 <= (eps * mean) ** 2:
+            return np.nan, np.nan
+        return m3 / m2 ** 1.5, m4 / m2 ** 2.0 - 3
 
 
 def zonal_stats_c(raw, labels, bands=None, start_label=1, n_labels=None):

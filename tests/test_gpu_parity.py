@@ -27,7 +27,7 @@ torch = pytest.importorskip("torch")
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_")))
 UNMASKED = [c for c in SLIC_CASES if not c.startswith("mask")]
 
 
@@ -285,3 +285,31 @@ def test_segment_end_to_end_quickstart(amd, oracle):
     ref = oracle.zonal_stats_numpy(before, lab)
     np.testing.assert_allclose(tbl["b2_mean"].to_numpy(), ref["mean"][:, 2], rtol=1e-5)
     np.testing.assert_allclose(tbl["b1_variance"].to_numpy(), ref["variance"][:, 1], rtol=1e-4, atol=1e-3)
+
+
+def test_zonal_skewness_kurtosis_vs_scipy_golden(amd):
+    """Second zonal pass (obia_zonal_moments_f32): skewness / kurtosis per (label, band) against SciPy's own output on
+    the float32 pixels (fixture from tests/golden/gen_goldens_moments.py).  SciPy computes the moments in float32, the
+    kernel in float64 about the float64 mean: 1e-4 absolute / relative covers float32 rounding of m2..m4 (the data are
+    a few hundred pixels per label).  NaN pattern (empty, all-NaN band, constant segment) must be identical."""
+    import os
+    from obia_amd.statistics import zonal_stats, create_objects
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "moments_96x131x5.npz"))
+    raw = z["dn"].astype(np.float32)
+    nanmask = np.unpackbits(z["nanmask"])[:raw.size].reshape(raw.shape).astype(bool)
+    raw[nanmask] = np.nan
+    lab = z["labels"]
+    st = zonal_stats(raw, lab, moments=True)
+    assert np.array_equal(np.isnan(st["skewness"]), np.isnan(z["skewness"]))
+    assert np.array_equal(np.isnan(st["kurtosis"]), np.isnan(z["kurtosis"]))
+    np.testing.assert_allclose(st["skewness"], z["skewness"], rtol=1e-4, atol=1e-4, equal_nan=True)
+    np.testing.assert_allclose(st["kurtosis"], z["kurtosis"], rtol=1e-4, atol=1e-4, equal_nan=True)
+    # device tensors and a band subset in another order give the same numbers
+    st2 = zonal_stats(dev(raw), dev(lab), bands=[4, 1], moments=True)
+    np.testing.assert_allclose(st2["skewness"].cpu().numpy(), st["skewness"][:, [4, 1]], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(st2["kurtosis"].cpu().numpy(), st["kurtosis"][:, [4, 1]], rtol=1e-12, equal_nan=True)
+    # the objects table carries the columns in the reference's order (segment_statistics.py:66-75)
+    df = create_objects(lab, raw, spectral_bands=[0, 2])
+    assert list(df.columns) == ["segment_id"] + [f"b{b}_{s}" for b in (0, 2)
+                                                  for s in ("mean", "variance", "min", "max", "skewness", "kurtosis")]
+    np.testing.assert_allclose(df["b2_skewness"].to_numpy(), st["skewness"][:, 2], rtol=1e-12, equal_nan=True)

@@ -17,7 +17,7 @@ from tests.metrics import adjusted_rand_index, label_disagreement
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_")))
 
 
 def load(name):
@@ -97,3 +97,19 @@ def test_zonal_stats_checker_matches_numpy_golden(oracle, name):
     np.testing.assert_allclose(sc["variance"], z["z_var"], rtol=1e-4, atol=1e-6 * 65535)
     np.testing.assert_array_equal(sc["min"], z["z_min"])
     np.testing.assert_array_equal(sc["max"], z["z_max"])
+
+
+def test_oracle_skew_kurtosis_match_scipy_golden():
+    """oracle.skew_kurtosis restates scipy.stats.skew / kurtosis (segment_statistics.py:173-175); the fixture was
+    produced by SciPy 1.15.3 on the float32 pixels of every label (tests/golden/gen_goldens_moments.py)."""
+    import os
+    from oracle import oracle
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "moments_96x131x5.npz"))
+    raw = z["dn"].astype(np.float32)
+    nanmask = np.unpackbits(z["nanmask"])[:raw.size].reshape(raw.shape).astype(bool)
+    raw[nanmask] = np.nan
+    st = oracle.zonal_stats_numpy(raw, z["labels"])
+    assert np.array_equal(np.isnan(st["skewness"]), np.isnan(z["skewness"]))
+    assert np.array_equal(np.isnan(st["kurtosis"]), np.isnan(z["kurtosis"]))
+    np.testing.assert_allclose(st["skewness"], z["skewness"], rtol=1e-6, atol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(st["kurtosis"], z["kurtosis"], rtol=1e-6, atol=1e-6, equal_nan=True)
