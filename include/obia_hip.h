@@ -130,6 +130,24 @@ int obia_zonal_moments_f32(obia_ctx *ctx, const float *raw_hwc, const int32_t *l
                            const int32_t *bands, int n_bands, int n_labels, int start_label,
                            double *skew_out, double *kurt_out);
 
+/* ---- next row f1: label raster -> polygon rings ------------------------------------------------------------------
+ * Replaces the vectorisation loop of create_segments (segment_boundaries.py:59-77: per segment id a full-raster
+ * mask + rasterio.features.shapes / GDAL polygonize, 4-connected) with one pass over the label raster.
+ *   labels      (H,W) int32 on the device; labels < start_label (masked pixels, -1 / 0) get no polygon
+ *   rings       every closed chain of pixel edges around a label, the label on the RIGHT of the direction of travel
+ *               (exterior rings clockwise on screen, holes counter-clockwise), in raster order of the ring's smallest
+ *               corner; ring r owns vertices [ring_offset[r], ring_offset[r+1]) of xy
+ *   xy          (x, y) int32 pixel-CORNER coordinates, (0,0) = top-left corner of the raster; vertices only where the
+ *               direction changes; first vertex repeated at the end.  Map coordinates = affine * (x, y).
+ *   ring_label  label of the ring; ring_is_hole 1 for an interior ring of that label.
+ * Two calls: _count returns the sizes, _rings fills caller-allocated DEVICE buffers of at least that capacity
+ * (ring_offset holds n_rings + 1 entries).  A label is one 4-connected component (the output of B1 / B3).          */
+int obia_polygon_count_i32_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, int W, int start_label,
+                               int64_t *n_rings_out, int64_t *n_vertices_out);
+int obia_polygon_rings_i32_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, int W, int start_label,
+                               int64_t cap_rings, int64_t cap_vertices, int32_t *ring_label, uint8_t *ring_is_hole,
+                               int64_t *ring_offset, int32_t *xy, int64_t *n_rings_out, int64_t *n_vertices_out);
+
 /* ---- B1': quickshift (the alternate method of create_segments, segment_boundaries.py:48-49) ------------------
  * Replaces `segments = quickshift(img_to_segment, **kwargs)`: skimage _quickshift.py:59-74 + _quickshift_cy.pyx.
  * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64

@@ -267,6 +267,13 @@ class Segments:
         self.method = method
         self.params = dict(kwargs)
 
+    def polygons(self, affine_transformation=None, start_label=1, ctx=None):
+        """Polygons of the label raster (the GeoDataFrame geometry of the reference's create_segments,
+        segment_boundaries.py:59-77): obia_amd.polygons.polygonize on ``_segments``.  Pass the image's
+        ``affine_transformation`` ([a, b, d, e, xoff, yoff]) for map coordinates."""
+        from .polygons import polygonize
+        return polygonize(self._segments, affine_transformation=affine_transformation, start_label=start_label, ctx=ctx)
+
     def write_segments(self, file_path):
         if hasattr(self.segments, "to_file"):
             self.segments.to_file(file_path)

@@ -56,3 +56,57 @@ def test_masked_seed_rule_properties(oracle):
     m[5, 7] = 1
     yx, _ = oracle.masked_grid_centroids(m, 10)
     assert yx.tolist() == [[5, 7]]
+
+
+def test_polygon_rings_known_answers():
+    """Hand-made label maps: a rectangle, an L shape, a ring with a hole (and the hole's own polygon), and two pixels of
+    one label that touch only diagonally (4-connectivity: two separate rings, as GDAL polygonize gives by default,
+    segment_boundaries.py:66)."""
+    from oracle.polygons import label_rings, rasterize_rings
+    lab = np.zeros((4, 5), np.int32)
+    lab[1:3, 1:4] = 7
+    r = label_rings(lab, start_label=1)
+    assert r == [(7, False, [(1, 1), (4, 1), (4, 3), (1, 3), (1, 1)])]
+    lab = np.array([[1, 1, 2],
+                    [1, 2, 2]], np.int32)
+    r = label_rings(lab, start_label=1)
+    assert r[0] == (1, False, [(0, 0), (2, 0), (2, 1), (1, 1), (1, 2), (0, 2), (0, 0)])
+    assert r[1] == (2, False, [(2, 0), (3, 0), (3, 2), (1, 2), (1, 1), (2, 1), (2, 0)])
+    donut = np.full((5, 5), 1, np.int32)
+    donut[2, 2] = 2
+    r = label_rings(donut, start_label=1)
+    assert r[0] == (1, False, [(0, 0), (5, 0), (5, 5), (0, 5), (0, 0)])
+    assert r[1] == (2, False, [(2, 2), (3, 2), (3, 3), (2, 3), (2, 2)])        # raster order of the smallest corner:
+    assert r[2] == (1, True, [(2, 2), (2, 3), (3, 3), (3, 2), (2, 2)])         # exterior of 2 before the hole of 1
+    diag = np.array([[3, 0],
+                     [0, 3]], np.int32)
+    r = label_rings(diag, start_label=1)
+    assert [x[2] for x in r] == [[(0, 0), (1, 0), (1, 1), (0, 1), (0, 0)], [(1, 1), (2, 1), (2, 2), (1, 2), (1, 1)]]
+    # background pixels that touch diagonally: the label's outline hugs the label at that corner (its two pixels there
+    # are not joined through the corner), so the enclosed background pixel is reached by the exterior ring -- one ring
+    # that passes the corner (1, 1) twice, no hole
+    inv = np.array([[0, 3, 3],
+                    [3, 0, 3],
+                    [3, 3, 3]], np.int32)
+    r = label_rings(inv, start_label=1)
+    assert len(r) == 1 and r[0][1] is False and r[0][2].count((1, 1)) == 2
+    for m in (lab, donut, diag, inv):
+        back = rasterize_rings(label_rings(m, start_label=1), *m.shape, fill=0)
+        assert np.array_equal(back, np.where(m >= 1, m, 0))
+
+
+def test_polygon_rings_properties_on_random_label_maps():
+    from oracle.polygons import label_rings, rasterize_rings
+    rs = np.random.RandomState(3)
+    for trial in range(5):
+        H, W = rs.randint(5, 30), rs.randint(5, 30)
+        lab = rs.randint(-1, 4, (H, W)).astype(np.int32)          # salt-and-pepper: many holes and diagonal contacts
+        rings = label_rings(lab, start_label=0)
+        area = {}
+        for L, hole, verts in rings:
+            a2 = sum(x0 * y1 - x1 * y0 for (x0, y0), (x1, y1) in zip(verts[:-1], verts[1:]))
+            assert (a2 < 0) == hole and verts[0] == verts[-1]
+            area[L] = area.get(L, 0) + a2
+        for L in np.unique(lab[lab >= 0]):
+            assert area[int(L)] == 2 * int((lab == L).sum())
+        assert np.array_equal(rasterize_rings(rings, H, W, fill=-1), np.where(lab >= 0, lab, -1))
