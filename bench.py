@@ -216,8 +216,8 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-                         # passes, gfx950 correction): 44.7 B/pixel measured in round 1 for C = 8 (profiles/r01_traffic.md)
-                         "traffic": round(44.7 * assign_px / max(1.0, sweeps)) if C == 8 else None,
+                         # passes, gfx950 correction): 48.7 B/pixel measured in round 1 for C = 8 (profiles/r01_traffic.md)
+                         "traffic": round(48.7 * assign_px / max(1.0, sweeps)) if C == 8 else None,
                          "traffic_source": "profiles/r01_traffic.md (PMC run of this command, not live)",
                          "bytes_per_pixel": bytes_per_px, "launches": int(sweeps), "avg_launch_ms": round(avg_launch_ms, 4),
                          "pixels_per_launch_avg": round(assign_px / max(1.0, sweeps), 1)},
