@@ -271,7 +271,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
-    __shared__ __attribute__((aligned(16))) float s_col[MAXC][CP];
     __shared__ unsigned long long s_acc[MAXC][AQ];
     __shared__ double s_tf[NT / 64][CP][65];    // 65: row stride that keeps the transposed reads conflict-free
     __shared__ int s_tkey[NT / 64][64];
@@ -366,10 +365,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             while (cur >= 0) {
                 // one round trip per list node: the whole record and the link are requested together
                 const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
-                const float4 r0 = src[0], r1 = src[1];
-                float4 rc[CP / 4];
-#pragma unroll
-                for (int q = 0; q < CP / 4; ++q) rc[q] = src[2 + q];
+                const float4 r0 = src[0], r1 = src[1];   // header only: the colours are read at visit time (scalar loads)
                 const int nxt = next[cur];
                 const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
                 const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
@@ -378,9 +374,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     if (slot < MAXC) {
                         float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
                         dh[0] = r0; dh[1] = r1;
-                        float4 *dc = reinterpret_cast<float4 *>(&s_col[slot][0]);
-#pragma unroll
-                        for (int q = 0; q < CP / 4; ++q) dc[q] = rc[q];
                     }
                 }
                 cur = nxt;
@@ -414,13 +407,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
         // operation is monotone, so lb <= spatial(pixel) <= d(pixel) for every pixel of the footprint.
         unsigned lbv[2];
+        int kkv[2];   // global centroid index of the lane's candidate
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int c = 64 * r + lane;
             unsigned key = 0xffffffffu;
+            kkv[r] = 0;
             if (c < nc) {
                 const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
                 const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+                kkv[r] = __float_as_int(h1.z);
                 const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
                 const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
                 if (y0 < fy1 && y1 > fy0 && x0 < fx1 && x1 > fx0) {
@@ -453,13 +449,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 }
             }
             // the candidate's header is wave-uniform: keep it in scalar registers
-            const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
-            const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
-            const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h0.x)));
-            const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h0.y)));
-            const int y0 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.z)), y1 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.w));
-            const int x0 = __builtin_amdgcn_readfirstlane(__float_as_int(h1.x)), x1 = __builtin_amdgcn_readfirstlane(__float_as_int(h1.y));
-            const int kk = __builtin_amdgcn_readfirstlane(__float_as_int(h1.z));
+            // the candidate's record is read from global memory at a wave-uniform address (its index is lifted out of the
+            // scoring lane with one readlane): the scalar unit loads header and colours into SGPRs, no VALU / LDS work
+            const int kk = (c & 64) ? __builtin_amdgcn_readlane(kkv[1], c & 63) : __builtin_amdgcn_readlane(kkv[0], c & 63);
+            const float4 *__restrict__ crec = reinterpret_cast<const float4 *>(cent + (size_t)kk * RS);
+            const float4 h0 = crec[0], h1 = crec[1];
+            const float cy = h0.x, cx = h0.y;
+            const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
+            const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
             // a window that covers the whole footprint (the common case: windows are ~4S wide) needs no per-pixel test
             const bool covers = (y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1);
             const float tx = cx - fx;
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     float col[CP];
 #pragma unroll
                     for (int q = 0; q < CP / 4; ++q) {
-                        const float4 t = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
+                        const float4 t = crec[2 + q];   // wave-uniform address: scalar loads, the colours stay in SGPRs
                         col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
                     }
 #pragma unroll
