@@ -148,6 +148,19 @@ int obia_polygon_rings_i32_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, i
                                int64_t cap_rings, int64_t cap_vertices, int32_t *ring_label, uint8_t *ring_is_hole,
                                int64_t *ring_offset, int32_t *xy, int64_t *n_rings_out, int64_t *n_vertices_out);
 
+/* ---- next row f4: consumers of the label raster -----------------------------------------------------------------
+ * obia_label_edges_u8_dev   : `slic_edge` (obia/utils/cost.py:44-48): edge[y][x] = 1 when the label differs from the
+ *                             pixel below or from the pixel to the right; n_edge_out = number of edge pixels (the
+ *                             percentile normalisation of cost.py:21-26 on a 0/1 image only needs that count).
+ * obia_sample_labels_i32_dev: the point-in-segment join of `label_segments` (obia/utils/utils.py:12-34) on a label
+ *                             raster.  inverse_affine6 = [a, b, d, e, xoff, yoff] (HOST pointer) maps map coordinates
+ *                             to pixel-corner coordinates (col = a*X + b*Y + xoff, row = d*X + e*Y + yoff); the point
+ *                             takes the label of pixel (floor(row), floor(col)), `outside_value` outside the raster.
+ *                             points_xy [n][2] float64 and labels_out [n] are DEVICE pointers.                     */
+int obia_label_edges_u8_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, int W, uint8_t *edge_out_hw, int64_t *n_edge_out);
+int obia_sample_labels_i32_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, int W, const double *inverse_affine6,
+                               const double *points_xy, int64_t n_points, int outside_value, int32_t *labels_out);
+
 /* ---- B1': quickshift (the alternate method of create_segments, segment_boundaries.py:48-49) ------------------
  * Replaces `segments = quickshift(img_to_segment, **kwargs)`: skimage _quickshift.py:59-74 + _quickshift_cy.pyx.
  * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64

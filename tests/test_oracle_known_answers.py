@@ -110,3 +110,19 @@ def test_polygon_rings_properties_on_random_label_maps():
         for L in np.unique(lab[lab >= 0]):
             assert area[int(L)] == 2 * int((lab == L).sum())
         assert np.array_equal(rasterize_rings(rings, H, W, fill=-1), np.where(lab >= 0, lab, -1))
+
+
+def test_edge_raster_known_answers():
+    """slic_edge (obia/utils/cost.py:44-48) on hand-made maps: an edge pixel is one whose lower or right neighbour has
+    another label; the percentile stretch of a 0/1 raster leaves it unchanged when between 2 % and 98 % of the pixels
+    are edges, and zeroes it when fewer than 2 % are (98th percentile 0 -> 0/0 -> 0)."""
+    from oracle.consumers import edge_raster, percentile_stretch
+    lab = np.array([[1, 1, 2],
+                    [1, 3, 3],
+                    [1, 3, 3]])
+    assert edge_raster(lab).tolist() == [[0, 1, 1], [1, 0, 0], [1, 0, 0]]
+    big = np.ones((100, 100), int); big[0, 0] = 2
+    assert not edge_raster(big).any()
+    v = np.arange(101, dtype=np.float64)
+    out = percentile_stretch(v)
+    assert out[0] == 0 and out[2] == 0 and out[100] == 1 and out[98] == 1 and abs(out[50] - 0.5) < 1e-12
