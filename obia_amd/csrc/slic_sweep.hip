@@ -673,8 +673,6 @@ template <int CP>
 static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color,
                           const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
     dim3 grid(b.total_tiles, b.nprob);
-    static const int ablate = getenv("OBIA_ABLATE") ? atoi(getenv("OBIA_ABLATE")) : 0;   // timing experiments only
-    if (ablate & 1) accumulate = 0;
     const int RQ = acc_record_qwords(CP);
 #define LAUNCH_ASSIGN_(M, I, F)                                                                                      \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
