@@ -33,12 +33,14 @@ namespace obia {
 #ifdef OBIA_STAMP
 // Diagnostic build only (make STAMP=1): per-phase wave-cycle sums, written to a buffer no other code reads.
 __device__ unsigned long long g_stamp[16];
-#define STAMP_DECL unsigned long long st_t = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_DECL unsigned long long st_t = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_cnt[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP_COUNT(i, v) st_cnt[i] += (v);
 #define STAMP(i) { const unsigned long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; }
-#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 8; ++st_i) atomicAdd(&g_stamp[st_i], st_acc[st_i]); atomicAdd(&g_stamp[15], 1ull); }
+#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 8; ++st_i) atomicAdd(&g_stamp[st_i], st_acc[st_i]); for (int st_i = 0; st_i < 6; ++st_i) atomicAdd(&g_stamp[8 + st_i], st_cnt[st_i]); atomicAdd(&g_stamp[15], 1ull); }
 #else
 #define STAMP_DECL
 #define STAMP(i)
+#define STAMP_COUNT(i, v)
 #define STAMP_FLUSH
 #endif
 
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         }
 
         STAMP(2)   // scoring
+        STAMP_COUNT(0, 1)   // footprints
         // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
         unsigned maxbest = 0x7f800000u;   // +inf
         for (;;) {
@@ -477,7 +480,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 cand[j] = cnd;
                 any |= cnd;
             }
+            STAMP_COUNT(1, 1)   // visits
+            STAMP_COUNT(4, __popcll(__ballot(cand[0])) + __popcll(__ballot(cand[1])) + __popcll(__ballot(cand[2])) + __popcll(__ballot(cand[3])))
             if (any) {
+                STAMP_COUNT(2, 1)   // visits that evaluate colours
                 if (!IGNORE_COLOR) {
                     float col[CP];
 #pragma unroll
@@ -520,6 +526,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             // largest best distance in the wave (+inf while a valid pixel is unassigned; invalid pixels hold -inf);
             // it can only have moved if some lane improved
             if (__ballot(improved)) {
+                STAMP_COUNT(3, 1)   // visits that improved a pixel
                 const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
                 maxbest = wave_umax(__float_as_uint(lm));
             }

@@ -25,3 +25,7 @@ tot = sum(out[i] for i in range(8))
 print("waves", out[15], "cycles/wave", tot / max(1, out[15]))
 for i, nme in enumerate(names):
     print(f"  {nme:14s} {out[i]/max(1,out[15]):10.0f} cyc/wave  {100.0*out[i]/tot:5.1f} %")
+cn = ["footprints", "visits", "visits evaluating colours", "visits improving a pixel", "candidate pixels (sum over visits)"]
+fp = max(1, out[8])
+for i, nme in enumerate(cn):
+    print(f"  {nme:36s} {out[8+i]:14d}  per footprint {out[8+i]/fp:8.2f}")
