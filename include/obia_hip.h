@@ -161,6 +161,16 @@ int obia_label_edges_u8_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, int 
 int obia_sample_labels_i32_dev(obia_ctx *ctx, const int32_t *labels_hw, int H, int W, const double *inverse_affine6,
                                const double *points_xy, int64_t n_points, int outside_value, int32_t *labels_out);
 
+/* ---- next row f3: GLCM texture statistics per (label, band) ------------------------------------------------------
+ * Restates calculate_textural_stats (segment_statistics.py:179-298) on the masked bounding-box crop of every segment,
+ * for the band PLANE the code evidently means (the reference indexes a column, :214; see oracle/glcm.py): crop of the
+ * band to the segment's bounding box, 0 outside the segment and at NaN pixels, uint8((v-min)/(max-min)*255) over that
+ * crop, GLCM at distance 2 in four directions, 256 levels, symmetric, normed, scikit-image's greycoprops, mean over the
+ * four angles.  out6 [6][n_labels][n_bands] float64 (device): contrast, dissimilarity, homogeneity, ASM, energy,
+ * correlation; NaN for an empty label or a band without a valid pixel.                                              */
+int obia_texture_stats_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_t *labels_hw, int H, int W, int C,
+                               const int32_t *bands, int n_bands, int n_labels, int start_label, double *out6);
+
 /* ---- B1': quickshift (the alternate method of create_segments, segment_boundaries.py:48-49) ------------------
  * Replaces `segments = quickshift(img_to_segment, **kwargs)`: skimage _quickshift.py:59-74 + _quickshift_cy.pyx.
  * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64

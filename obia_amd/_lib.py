@@ -51,6 +51,7 @@ _SIGNATURES = {
     "obia_zonal_stats_f32_dev": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "obia_zonal_moments_f32_dev": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
     "obia_zonal_moments_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P]),
+    "obia_texture_stats_f32_dev": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P]),
     "obia_label_edges_u8_dev": (_I, [_P, _P, _I, _I, _P, _P]),
     "obia_sample_labels_i32_dev": (_I, [_P, _P, _I, _I, _P, _P, ctypes.c_int64, _I, _P]),
     "obia_polygon_count_i32_dev": (_I, [_P, _P, _I, _I, _I, _P, _P]),

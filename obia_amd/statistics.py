@@ -7,7 +7,6 @@ GPU pass (libobia_hip.so: obia_zonal_stats_f32), plus skewness / kurtosis from a
 (obia_zonal_moments_f32).
 """
 import ctypes
-import warnings
 
 import numpy as np
 
@@ -109,6 +108,51 @@ def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None,
     return out
 
 
+TEXTURE_PROPS = ("contrast", "dissimilarity", "homogeneity", "ASM", "energy", "correlation")
+
+
+def texture_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None):
+    """GLCM texture statistics per (label, band): dict prop -> (N, B) float64 for contrast, dissimilarity, homogeneity,
+    ASM, energy, correlation (calculate_textural_stats, segment_statistics.py:179-298, on the band plane -- see
+    oracle/glcm.py for the one place where this departs from the reference's indexing).  NumPy in -> NumPy out, CUDA
+    tensors in -> CUDA tensors out (libobia_hip.so: obia_texture_stats_f32_dev)."""
+    if torch is None:
+        raise ImportError("obia_amd.statistics.texture_stats needs torch for device memory")
+    lib = _lib.load()
+    is_t = _is_torch(raw)
+    if is_t:
+        if not raw.is_cuda:
+            raise ValueError("torch inputs must live on the GPU")
+        r = raw.to(torch.float32).contiguous()
+    else:
+        c0 = ctx or _lib.default_context(0)
+        r = torch.as_tensor(np.ascontiguousarray(raw, dtype=np.float32), device=f"cuda:{c0.device}")
+    if r.dim() != 3:
+        raise ValueError("raw must be (H,W,C)")
+    H, W, C = r.shape
+    lab = torch.as_tensor(labels, device=r.device).to(torch.int32).contiguous()
+    if tuple(lab.shape) != (H, W):
+        raise ValueError("labels must have the raster's (H,W) shape")
+    if n_labels is None:
+        n_labels = int(lab.max().item()) - start_label + 1
+    n_labels = max(int(n_labels), 0)
+    bl = list(range(C)) if bands is None else [int(b) for b in bands]
+    for b in bl:
+        if b < 0 or b >= C:
+            raise IndexError(f"Band index {b} out of range. Available bands indices: 0 to {C - 1}.")
+    B = len(bl)
+    barr = np.ascontiguousarray(bl, np.int32)
+    out = torch.full((6, n_labels, B), float("nan"), dtype=torch.float64, device=r.device)
+    c = ctx or _lib.default_context(r.device.index or 0)
+    torch.cuda.current_stream(r.device.index or 0).synchronize()
+    if n_labels > 0 and B > 0:
+        _lib.check(lib.obia_texture_stats_f32_dev(c.handle, r.data_ptr(), lab.data_ptr(), H, W, C, _lib.np_ptr(barr), B,
+                                                  n_labels, int(start_label), out.data_ptr()))
+    res = {p: (out[i] if is_t else out[i].cpu().numpy()) for i, p in enumerate(TEXTURE_PROPS)}
+    res["bands"] = bl
+    return res
+
+
 def stats_columns(spectral_bands, textural_bands=(), calc_mean=True, calc_variance=True, calc_min=True, calc_max=True,
                   calc_skewness=True, calc_kurtosis=True, calc_contrast=True, calc_dissimilarity=True,
                   calc_homogeneity=True, calc_ASM=True, calc_energy=True, calc_correlation=True):
@@ -137,8 +181,7 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
     ``segments``: the label raster from create_segments (one 4-connected component per label, so "pixels
     inside polygon p" are "pixels carrying label p").  ``image``: object with ``img_data`` or
     the raw (H,W,C) array.  Returns a pandas DataFrame whose columns follow the reference's order;
-    mean/variance/min/max and skewness/kurtosis come from the GPU passes.  The GLCM texture columns are the next
-    stage outside this path: requested texture columns are present and NaN, with a warning.
+    mean/variance/min/max, skewness/kurtosis and the six GLCM texture statistics come from the GPU passes.
     """
     import pandas as pd
     if not (calculate_spectral or calculate_textural or calculate_structural or calculate_radiometric):
@@ -162,18 +205,19 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
                          calc_kurtosis, calc_contrast, calc_dissimilarity, calc_homogeneity, calc_ASM, calc_energy,
                          calc_correlation)
     data = {"segment_id": np.arange(1, n + 1)}
-    pending = []
     for j, b in enumerate(spectral_bands):
         for name, key, on in (("mean", "mean", calc_mean), ("variance", "variance", calc_variance),
                               ("min", "min", calc_min), ("max", "max", calc_max),
                               ("skewness", "skewness", calc_skewness), ("kurtosis", "kurtosis", calc_kurtosis)):
             if on:
                 data[f"b{b}_{name}"] = st[key][:, j]
-    for c in cols:
-        if c not in data:
-            data[c] = np.full(n, np.nan)
-            pending.append(c)
-    if pending:
-        warnings.warn("obia_amd: GLCM texture columns are not computed in this version and are NaN "
-                      f"({len(pending)} columns)", RuntimeWarning, stacklevel=2)
+    if tex_bands:
+        tx = texture_stats(img_data, segments, bands=tex_bands, start_label=start_label, n_labels=n, ctx=ctx)
+        tx = {k: (v.cpu().numpy() if _is_torch(v) else v) for k, v in tx.items()}
+        for j, b in enumerate(tex_bands):
+            for name, on in (("contrast", calc_contrast), ("dissimilarity", calc_dissimilarity),
+                             ("homogeneity", calc_homogeneity), ("ASM", calc_ASM), ("energy", calc_energy),
+                             ("correlation", calc_correlation)):
+                if on:
+                    data[f"b{b}_{name}"] = tx[name][:, j]
     return pd.DataFrame(data, columns=cols)

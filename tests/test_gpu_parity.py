@@ -27,7 +27,7 @@ torch = pytest.importorskip("torch")
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_")))
 UNMASKED = [c for c in SLIC_CASES if not c.startswith("mask")]
 
 
@@ -313,3 +313,33 @@ def test_zonal_skewness_kurtosis_vs_scipy_golden(amd):
     assert list(df.columns) == ["segment_id"] + [f"b{b}_{s}" for b in (0, 2)
                                                   for s in ("mean", "variance", "min", "max", "skewness", "kurtosis")]
     np.testing.assert_allclose(df["b2_skewness"].to_numpy(), st["skewness"][:, 2], rtol=1e-12, equal_nan=True)
+
+
+def test_glcm_texture_vs_skimage_golden(amd, oracle):
+    """obia_texture_stats_f32_dev against scikit-image's own greycomatrix / greycoprops output (fixture) -- integer pair
+    sums are exact, so 1e-9 relative -- on segments that include a single pixel, a two-row strip (the vertical offset
+    finds no pair), a constant segment and a band without a valid pixel; then on a coarse partition whose bounding
+    boxes exceed 4096 pixels (dense-matrix path) against the CPU restatement; then through create_objects."""
+    import os
+    from obia_amd.statistics import texture_stats, create_objects, TEXTURE_PROPS
+    from oracle import glcm
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "glcm_90x110x3.npz"))
+    raw = z["dn"].astype(np.float32)
+    nanmask = np.unpackbits(z["nanmask"])[:raw.size].reshape(raw.shape).astype(bool)
+    raw[nanmask] = np.nan
+    lab = z["labels"]
+    st = texture_stats(raw, lab)
+    for p in TEXTURE_PROPS:
+        assert np.array_equal(np.isnan(st[p]), np.isnan(z[p])), p
+        np.testing.assert_allclose(st[p], z[p], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=p)
+    # big bounding boxes (> 4096 px) and a band subset, device tensors in
+    yy, xx = np.mgrid[0:raw.shape[0], 0:raw.shape[1]]
+    coarse = ((yy // 75) * 2 + xx // 80 + 1).astype(np.int32)
+    st2 = texture_stats(dev(raw), dev(coarse), bands=[2, 0])
+    chk = glcm.texture_stats(raw, coarse, bands=[2, 0])
+    for p in TEXTURE_PROPS:
+        np.testing.assert_allclose(st2[p].cpu().numpy(), chk[p], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=p)
+    df = create_objects(lab, raw, spectral_bands=[0], textural_bands=[1], calculate_textural=True, calc_skewness=False,
+                        calc_kurtosis=False)
+    assert list(df.columns) == ["segment_id", "b0_mean", "b0_variance", "b0_min", "b0_max"] + [f"b1_{p}" for p in TEXTURE_PROPS]
+    np.testing.assert_allclose(df["b1_energy"].to_numpy(), st["energy"][:, 1], rtol=1e-12, equal_nan=True)

@@ -17,7 +17,7 @@ from tests.metrics import adjusted_rand_index, label_disagreement
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_")))
 
 
 def load(name):
@@ -113,3 +113,18 @@ def test_oracle_skew_kurtosis_match_scipy_golden():
     assert np.array_equal(np.isnan(st["kurtosis"]), np.isnan(z["kurtosis"]))
     np.testing.assert_allclose(st["skewness"], z["skewness"], rtol=1e-6, atol=1e-6, equal_nan=True)
     np.testing.assert_allclose(st["kurtosis"], z["kurtosis"], rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
+def test_oracle_glcm_matches_skimage_golden():
+    """oracle/glcm.py restates greycomatrix / greycoprops (segment_statistics.py:260-296) on the quantised bounding-box
+    crop of every segment; the fixture was produced by scikit-image 0.18.3 (tests/golden/gen_goldens_glcm.py)."""
+    import os
+    from oracle import glcm
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "glcm_90x110x3.npz"))
+    raw = z["dn"].astype(np.float32)
+    nanmask = np.unpackbits(z["nanmask"])[:raw.size].reshape(raw.shape).astype(bool)
+    raw[nanmask] = np.nan
+    st = glcm.texture_stats(raw, z["labels"])
+    for p in glcm.PROPS:
+        assert np.array_equal(np.isnan(st[p]), np.isnan(z[p])), p
+        np.testing.assert_allclose(st[p], z[p], rtol=1e-10, atol=1e-12, equal_nan=True, err_msg=p)
