@@ -255,6 +255,11 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits, __float_as_uint(local_max));
 }
 
+__global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntot) keys[i] = (i < nkeys && (i & 1) == 0) ? 0xffffffffu : 0u;
+}
+
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
                           int to_lab, float ratio, std::vector<int> *skip) {
     (void)Hs;
@@ -267,10 +272,8 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     if (!d_keys) return OBIA_E_NOMEM;
     unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
     std::vector<unsigned> host(ntot);
-    for (size_t i = 0; i < (size_t)np * C; ++i) { host[2 * i] = 0xffffffffu; host[2 * i + 1] = 0u; }
-    for (size_t i = nkeys; i < ntot; ++i) host[i] = 0;
-    OBIA_HIP_TRY(hipMemcpyAsync(d_keys, host.data(), ntot * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `host` is pageable memory
+    // (min, max) key pairs start at (0xffffffff, 0), the flags at 0: initialised on the device, no host round trip
+    hipLaunchKernelGGL(keys_init_kernel, dim3(cdiv((long long)ntot, 256)), dim3(256), 0, ctx->stream, d_keys, (int)nkeys, (int)ntot);
     int maxh = 1;
     long long maxpix = 1;
     for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; long long n = (long long)w.h * w.w; if (n > maxpix) maxpix = n; }
