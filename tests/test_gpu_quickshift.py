@@ -51,3 +51,17 @@ def test_quickshift_vs_oracle_nolab_and_device_entry(oracle):
         quickshift(np.zeros((8, 8, 4), np.float32), convert2lab=True)
     with pytest.raises(NotImplementedError):
         quickshift(img, kernel_size=9)
+
+
+def test_quickshift_device_noise_matches_the_goldens_away_from_ties():
+    """rng="device" draws the tie-breaking noise on the GPU (not NumPy's stream): on natural images densities never tie
+    to within 1e-5, so the partition is that of the golden vectors to the same tolerance."""
+    from obia_amd.segmentation import quickshift
+    z = np.load(os.path.join(GOLD, "quickshift_small.npz"))
+    ks, md = z["par0"]
+    raw = z["raw0"].astype(np.float32)
+    lab = quickshift(torch.as_tensor(raw).cuda(), ratio=1.0, kernel_size=float(ks), max_dist=float(md), convert2lab=True,
+                     rng="device", _normalize_bands=True).cpu().numpy()
+    assert adjusted_rand_index(lab, z["labels0"]) >= 0.99
+    with pytest.raises(ValueError):
+        quickshift(raw, rng="device")
