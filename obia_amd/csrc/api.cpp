@@ -109,7 +109,8 @@ int obia_slic_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, cons
                 // segment_size = mask.sum() / n_centroids  |  prod(shape) / n_centroids  (slic_superpixels.py:321-326)
                 const double segment_size = (double)b.probs[0].n_valid / (double)b.probs[0].K;
                 const int min_size = (int)(params->min_size_factor * segment_size);
-                const int max_size = (int)(params->max_size_factor * segment_size);
+                const double mxd = params->max_size_factor * segment_size;
+                const int max_size = mxd >= 2147483647.0 ? 2147483647 : (mxd < 1.0 ? 1 : (int)mxd);
                 rc = enforce_connectivity_dev(ctx, b.d_labels, H, W, min_size, max_size, params->start_label, labels_out, &n_labels);
             } else {
                 hipError_t e = hipMemcpyAsync(labels_out, b.d_labels, sizeof(int32_t) * (size_t)H * W, hipMemcpyDeviceToDevice, ctx->stream);

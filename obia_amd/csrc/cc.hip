@@ -12,11 +12,13 @@
 //     label -- i.e. belongs to a component whose first pixel precedes this BFS's start pixel.  Small
 //     components are rare and small, so one lane replays the BFS of each of them exactly; chains
 //     small -> small -> ... -> survivor are resolved afterwards.
-// Deliberately NOT reproduced (DESIGN.md "connectivity"): the split of components that reach max_size
-// (the BFS of the reference stops there and the rest is re-seeded, an order-dependent cut that no
-// BASELINE configuration triggers), and the exact bookkeeping of small components that find no
-// labelled neighbour on their first BFS and are re-seeded from a later pixel (replayed here with the
-// same start pixels, but neighbours are classified by root order only).
+//   * a component that reaches max_size is cut the way the reference cuts it: its BFS (neighbour order x+1, x-1, y+1,
+//     y-1, first-in first-out) stops at max_size pixels, the raster scan later meets the next unlabelled pixel of the
+//     region and starts another capped BFS from there.  Such components are rare; one lane replays each of them
+//     (cc_split_kernel) and rewrites parent / size so that every piece is a component of its own for the stages below.
+// Not reproduced exactly (DESIGN.md "connectivity"): the bookkeeping of small components that find no labelled
+// neighbour on their first BFS and are re-seeded from a later pixel (replayed here with the same start pixels, but
+// neighbours are classified by root order only).
 #include "slic.hpp"
 
 namespace obia {
@@ -237,23 +239,104 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProbl
                                                                    int *__restrict__ counters /*[0]=n_small [1]=small_px*/) {
     __shared__ int s_w[SCAN_NT / 64];
     const long long base = (long long)blockIdx.x * SCAN_CHUNK;
-    int c = 0, nsmall = 0, spx = 0;
+    int c = 0, nsmall = 0, spx = 0, nbig = 0;
     for (int j = 0; j < SCAN_PER; ++j) {
         const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
         if (i < n && parent[i] == (int)i) {
             const int sz = size[i];
-            const int min_size = probs[find_prob(probs, nprob, i)].min_size;
-            if (sz >= min_size) c += 1;
+            const CcProblem &P = probs[find_prob(probs, nprob, i)];
+            if (sz >= P.min_size) c += 1;
             else { nsmall += 1; spx += sz; }
+            if (sz >= P.max_size && sz > 1) nbig += 1;   // reaches max_size: the reference cuts it (cc_split_kernel)
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); nsmall += __shfl_xor(nsmall, off); spx += __shfl_xor(spx, off); }
+    for (int off = 32; off > 0; off >>= 1) {
+        c += __shfl_xor(c, off); nsmall += __shfl_xor(nsmall, off); spx += __shfl_xor(spx, off); nbig += __shfl_xor(nbig, off);
+    }
     if ((threadIdx.x & 63) == 0) {
         s_w[threadIdx.x >> 6] = c;
         if (nsmall) { atomicAdd(&counters[0], nsmall); atomicAdd(&counters[1], spx); }
+        if (nbig) atomicAdd(&counters[6], nbig);
     }
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// ---- components that reach max_size -----------------------------------------------------------------------------------
+// 1. every root whose component reaches max_size gets an index b (big_root[b], queue offset); newlab[root] = b
+__global__ __launch_bounds__(256) void cc_big_list_kernel(const CcProblem *__restrict__ probs, int nprob, const int *__restrict__ parent,
+                                                          const int *__restrict__ size, long long n, int *__restrict__ newlab,
+                                                          int *__restrict__ big_root, int *__restrict__ big_qoff,
+                                                          int *__restrict__ big_box, int *__restrict__ counters /*[6] list cursor, [7] queue cursor*/) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || parent[i] != (int)i) return;
+    const int sz = size[i];
+    if (!(sz >= probs[find_prob(probs, nprob, i)].max_size && sz > 1)) return;
+    const int b = atomicAdd(&counters[6], 1);
+    big_root[b] = (int)i;
+    big_qoff[b] = atomicAdd(&counters[7], sz);
+    big_box[4 * b] = 0x7fffffff; big_box[4 * b + 1] = -1; big_box[4 * b + 2] = 0x7fffffff; big_box[4 * b + 3] = -1;
+    newlab[i] = b;
+}
+
+// 2. the pixels of those components are marked parent = -2 - root ("in the region, not yet in a piece") and their bounding
+// boxes collected
+__global__ __launch_bounds__(256) void cc_big_mark_kernel(const CcProblem *__restrict__ probs, int nprob, int *__restrict__ parent,
+                                                          const int *__restrict__ size, long long n, const int *__restrict__ newlab,
+                                                          int *__restrict__ big_box) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = parent[i];
+    if (r < 0) return;
+    const int sz = size[r];
+    const CcProblem &P = probs[find_prob(probs, nprob, r)];
+    if (!(sz >= P.max_size && sz > 1)) return;
+    const int b = newlab[r];
+    const int y = (int)((i - P.pix_off) / P.W), x = (int)((i - P.pix_off) - (long long)y * P.W);
+    atomicMin(&big_box[4 * b], y); atomicMax(&big_box[4 * b + 1], y);
+    atomicMin(&big_box[4 * b + 2], x); atomicMax(&big_box[4 * b + 3], x);
+    parent[i] = -2 - r;   // (-1 is the parent of masked pixels)
+}
+
+// 3. one lane per component replays the reference: raster scan of the bounding box, capped BFS from every pixel that is
+// still unassigned.  parent of a piece = its start pixel (its smallest index: the scan picks the smallest unassigned
+// pixel, and a BFS only takes unassigned ones), size[start] = pixels of the piece.
+__global__ __launch_bounds__(64) void cc_split_kernel(const CcProblem *__restrict__ probs, int nprob, int *__restrict__ parent,
+                                                      int *__restrict__ size, const int *__restrict__ big_root,
+                                                      const int *__restrict__ big_qoff, const int *__restrict__ big_box, int n_big,
+                                                      int *__restrict__ queue) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_big) return;
+    const int R = big_root[b], region = -2 - R;
+    const CcProblem P = probs[find_prob(probs, nprob, R)];
+    const int H = P.H, W = P.W, base = (int)P.pix_off, cap = P.max_size;
+    int *q = queue + big_qoff[b];
+    const int y0 = big_box[4 * b], y1 = big_box[4 * b + 1], x0 = big_box[4 * b + 2], x1 = big_box[4 * b + 3];
+    for (int sy = y0; sy <= y1; ++sy)
+        for (int sx = x0; sx <= x1; ++sx) {
+            const int start = base + sy * W + sx;
+            if (parent[start] != region) continue;
+            int cnt = 1, visited = 0;
+            q[0] = start;
+            parent[start] = start;
+            while (visited < cnt && cnt < cap) {
+                const int p = q[visited];
+                const int y = (p - base) / W, x = (p - base) - y * W;
+                for (int d = 0; d < 4; ++d) {
+                    const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
+                    const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
+                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                    const int nb = base + yy * W + xx;
+                    if (parent[nb] == region) {
+                        parent[nb] = start;
+                        q[cnt++] = nb;
+                        if (cnt >= cap) break;
+                    }
+                }
+                ++visited;
+            }
+            size[start] = cnt;
+        }
 }
 
 // exclusive scan of block_sums in place, single workgroup; total -> counters[2]
@@ -461,6 +544,26 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
     int hc[8];
     OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));   // also orders the pageable `probs` upload
+    if (hc[6] > 0) {
+        // some component reaches max_size: cut it the way the reference's capped BFS does, then count again
+        const int n_big = hc[6];
+        int *big_root = A.get<int>(n_big), *big_qoff = A.get<int>(n_big), *big_box = A.get<int>(4 * (size_t)n_big);
+        if (!big_root || !big_qoff || !big_box) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+        hipLaunchKernelGGL(cc_big_list_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_probs, np, parent, size, n, newlab,
+                           big_root, big_qoff, big_box, counters);
+        int hb[8];
+        OBIA_TRY(read_back(ctx, hb, counters, sizeof(hb)));
+        int *bqueue = A.get<int>(hb[7] > 0 ? hb[7] : 1);
+        if (!bqueue) return OBIA_E_NOMEM;
+        hipLaunchKernelGGL(cc_big_mark_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_probs, np, parent, size, n, newlab, big_box);
+        hipLaunchKernelGGL(cc_split_kernel, dim3(cdiv(n_big, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, size, big_root, big_qoff,
+                           big_box, n_big, bqueue);
+        OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+        hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters);
+        hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
+        OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));
+    }
     const int n_small = hc[0], small_px = hc[1], n_surv = hc[2];
     int *small_list = A.get<int>(n_small > 0 ? n_small : 1);
     int *small_qoff = A.get<int>(n_small > 0 ? n_small : 1);
@@ -497,8 +600,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
 
 int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size, int max_size,
                              int start_label, int32_t *labels_out, int *h_n_labels_out) {
-    (void)max_size;   // components are never split at max_size (see the header of this file)
-    std::vector<CcProblem> probs(1, CcProblem{H, W, 0, min_size, 0});
+    std::vector<CcProblem> probs(1, CcProblem{H, W, 0, min_size, max_size > 0 ? max_size : 1});
     return enforce_connectivity_batch(ctx, probs, labels_in, (long long)H * W, start_label, labels_out, h_n_labels_out);
 }
 

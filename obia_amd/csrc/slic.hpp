@@ -86,7 +86,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b);
 
 // Connectivity enforcement on a batch of dense label maps laid out back to back (pix_off); labels come
 // out consecutive over the whole batch, in problem order then raster order of each component's first pixel.
-struct CcProblem { int H, W; long long pix_off; int min_size; int pad; };
+struct CcProblem { int H, W; long long pix_off; int min_size; int max_size; };   // component sizes: merge below min, cut at max
 int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
                                long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out);
 

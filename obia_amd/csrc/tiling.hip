@@ -333,7 +333,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         for (int p = 0; p < np; ++p) {
             const SlicProblem &P = b.probs[p];
             const double segment_size = P.K > 0 ? (double)P.n_valid / (double)P.K : 1.0;
-            cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp.min_size_factor * segment_size), 0};
+            const double mxd = S.sp.max_size_factor * segment_size;
+            const int mx = mxd >= 2147483647.0 ? 2147483647 : (int)mxd;
+            cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp.min_size_factor * segment_size), mx > 0 ? mx : 1};
         }
         OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new));
     } else {
