@@ -63,7 +63,7 @@ typedef struct obia_slic_params {
     int32_t max_num_iter;          /* scikit-image `max_num_iter` (`max_iter` before 0.19)            */
     int32_t convert2lab;           /* -1 auto (Lab iff C == 3), 0, 1                                  */
     int32_t enforce_connectivity;
-    int32_t slic_zero;             /* 1 -> OBIA_E_UNSUPPORTED in this version                         */
+    int32_t slic_zero;             /* 1 = SLIC-zero: colour term / max colour distance of the cluster  */
     int32_t start_label;           /* 0 or 1                                                          */
     int32_t normalize_bands;       /* 1: apply normalize_band (segment_boundaries.py:11-16,32-33) to
                                       every band before segmenting, as create_segments does           */

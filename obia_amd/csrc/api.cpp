@@ -24,7 +24,6 @@ int check_slic_args(const float *img, int H, int W, int C, const obia_slic_param
     if (!(p->compactness > 0.0)) { set_error("compactness must be positive"); return OBIA_E_INVALID; }
     if (p->n_segments <= 0) { set_error("n_segments must be positive"); return OBIA_E_INVALID; }
     if (p->max_num_iter < 0) { set_error("max_num_iter must be >= 0"); return OBIA_E_INVALID; }
-    if (p->slic_zero) { set_error("slic_zero=True is not implemented in this version"); return OBIA_E_UNSUPPORTED; }
     return OBIA_OK;
 }
 
@@ -39,6 +38,7 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.start_label = p->start_label;
     b.max_iter = p->max_num_iter;
     b.exit_on_fixed_point = p->exit_on_fixed_point != 0;
+    b.slic_zero = p->slic_zero != 0;
     b.total_pix = (long long)H * W;
     SlicProblem P{};
     P.H = H; P.W = W; P.pix_off = 0;

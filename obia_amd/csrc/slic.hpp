@@ -62,6 +62,7 @@ struct SlicBatch {
     unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
     double fscale = 1.0;
     bool exit_on_fixed_point = false;
+    bool slic_zero = false;            // SLIC-zero: colour term scaled by the cluster's largest colour distance so far
 };
 
 // Feature preparation for every problem of the batch: per-band min/max of its window, then

@@ -57,7 +57,7 @@ constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64
 template <int G>
 __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__restrict__ probs,
                                                         const int *__restrict__ cent_prob, int total_cent, int CP,
-                                                        int first, const float *__restrict__ seed,
+                                                        int first, int slic_zero, const float *__restrict__ seed,
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
                                                         int *__restrict__ next, int *__restrict__ head_other,
@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
         moved |= __float_as_uint(cy) != __float_as_uint(old_cy) || __float_as_uint(cx) != __float_as_uint(old_cx);
     }
     if (!live || q != 0) return;
+    // SLIC-zero: slot 7 of the record carries max_dist_color[k] from sweep to sweep (1 before the first sweep; raised by
+    // slic_maxdist_kernel after every centroid update); otherwise the slot is unused
+    const float mdc = slic_zero ? ((first || slic_zero == 2) ? 1.0f : rec[7]) : 0.0f;   // 2: first sweep of the colour pass
     if (bin_stamp && moved && !first && old_cy == old_cy && old_cx == old_cx) {   // the bin it leaves
         int oby = (int)(old_cy / (float)P.sy), obx = (int)(old_cx / (float)P.sx);
         oby = oby < 0 ? 0 : (oby >= P.ncy ? P.ncy - 1 : oby);
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     float4 *hrec = reinterpret_cast<float4 *>(rec);   // records are 16-byte aligned (RS is a multiple of 4)
     if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
         hrec[0] = make_float4(cy, cx, 0.0f, 0.0f);
-        hrec[1] = make_float4(0.0f, 0.0f, __int_as_float(k), 0.0f);
+        hrec[1] = make_float4(0.0f, 0.0f, __int_as_float(k), mdc);
         next[k] = -1;
         return;
     }
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
     float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
     hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
-    hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(k), 0.0f);
+    hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(k), mdc);
     int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
     by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
     bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
@@ -197,7 +200,7 @@ __device__ __forceinline__ void global_accumulate(unsigned long long *__restrict
 
 // Fallback for a tile whose candidate set does not fit the LDS slots: every lane scans the bins around
 // each of its pixels directly in global memory.  Same arithmetic, no staging.
-template <int CP, bool MASKED, bool IGNORE_COLOR>
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool SLICZERO>
 __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *__restrict__ feat,
                           const uint8_t *__restrict__ mask, const float *__restrict__ cent,
                           const int *__restrict__ head, const int *__restrict__ next, int32_t *__restrict__ labels,
@@ -231,7 +234,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                         float dc = 0.0f;
 #pragma unroll
                         for (int ch = 0; ch < CP; ++ch) { const float t = f[ch] - rec[CENT_REC + ch]; dc += t * t; }
-                        d += dc;
+                        d += SLICZERO ? dc / rec[7] : dc;
                     }
                     if (d < best || (d == best && cur < bk)) { best = d; bk = cur; }
                 }
@@ -252,7 +255,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 }
 
 // K2: the sweep.  grid = (max tiles per problem, nprob).
-template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT>
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     STAMP(0)   // staging
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
-        slow_tile<CP, MASKED, IGNORE_COLOR>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
+        slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
                                             start_label, fscale);
         return;
     }
@@ -499,7 +502,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                             const float t = f[j][ch] - col[ch];
                             dc += t * t;
                         }
-                        dv[j] += dc;
+                        // SLIC-zero: the colour term is scaled by the largest colour distance seen in this cluster so far
+                        // (_slic.pyx: dist_center += dist_color / max_dist_color[k])
+                        dv[j] += SLICZERO ? dc / h1.w : dc;
                     }
                 }
                 // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k).  Exact ties are
@@ -671,6 +676,39 @@ extern "C" void obia_debug_stamps(unsigned long long *out16, int reset) {
 }
 #endif
 
+// SLIC-zero: after a centroid update, max_dist_color[k] = max(max_dist_color[k], colour distance of every pixel of
+// cluster k to the NEW centroid) (_slic.pyx, the loop after the centroid recomputation; oracle/obia_oracle.c:273-286).
+// The value lives in slot 7 of the centroid record; distances are >= 0, so the float bit pattern orders like the value.
+template <int CP, bool MASKED>
+__global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__restrict__ probs, const float *__restrict__ feat,
+                                                           const uint8_t *__restrict__ mask, const int32_t *__restrict__ labels,
+                                                           float *__restrict__ cent, int start_label) {
+    constexpr int RS = CENT_REC + CP;
+    const SlicProblem P = probs[blockIdx.y];
+    for (int y = blockIdx.x; y < P.H; y += gridDim.x)
+        for (int x = threadIdx.x; x < P.W; x += 256) {
+            const long long pix = P.pix_off + (long long)y * P.W + x;
+            if (MASKED && mask[pix] == 0) continue;
+            const int l = labels[pix];
+            if (l < start_label) continue;
+            const int k = l - start_label + P.cent_off;
+            const float *rec = cent + (size_t)k * RS;
+            float dc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < CP / 4; ++q) {
+                const float4 f = reinterpret_cast<const float4 *>(feat + pix * CP)[q];
+                const float4 c = reinterpret_cast<const float4 *>(rec + CENT_REC)[q];
+                float t;
+                t = f.x - c.x; dc += t * t;
+                t = f.y - c.y; dc += t * t;
+                t = f.z - c.z; dc += t * t;
+                t = f.w - c.w; dc += t * t;
+            }
+            unsigned *slot = reinterpret_cast<unsigned *>(cent + (size_t)k * RS + 7);
+            if (__float_as_uint(dc) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(dc));
+        }
+}
+
 struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; null when the option is off)
     int *bin_stamp = nullptr, *tile_lp = nullptr, *cache_k = nullptr;
     unsigned long long *cache_q = nullptr;
@@ -681,12 +719,19 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
                           const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
     dim3 grid(b.total_tiles, b.nprob);
     const int RQ = acc_record_qwords(CP);
-#define LAUNCH_ASSIGN_(M, I, F)                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs,    \
+#define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
                        accum_color, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,   \
                        use_cache, px_counter)
-#define LAUNCH_ASSIGN(M, I) do { if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true); else LAUNCH_ASSIGN_(M, I, false); } while (0)
+    // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
+    // the fixed-point cache (the per-cluster scale changes after the records were compared)
+#define LAUNCH_ASSIGN(M, I)                                                                                          \
+    do {                                                                                                             \
+        if (b.slic_zero && !(I)) LAUNCH_ASSIGN_(M, false, false, true);                                              \
+        else if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true, false);                                                    \
+        else LAUNCH_ASSIGN_(M, I, false, false);                                                                     \
+    } while (0)
     if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
     else LAUNCH_ASSIGN(false, false);
 #undef LAUNCH_ASSIGN
@@ -727,6 +772,9 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     }
     bool first = true;
     int sweep_no = 0;
+    int maxh_z = 1;
+    for (auto &P : b.probs) if (P.H > maxh_z) maxh_z = P.H;
+    if (maxh_z > 4096) maxh_z = 4096;
     OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
     for (int pass = 0; pass < passes; ++pass) {
         const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
@@ -735,16 +783,35 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
             int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
             int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
             ++sweep_no;   // sweep ids start at 1
+            // SLIC-zero: the per-cluster colour scale restarts at 1 with the colour pass and is carried afterwards
+            const int zmode = (b.slic_zero && !ignore_color) ? (it == 0 ? 2 : 1) : 0;
             if (RQ == 16)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv((long long)b.total_cent * 16, 256)), dim3(256), 0,
-                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, b.d_seed, b.d_acc,
+                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
                                    1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv((long long)b.total_cent * 32, 256)), dim3(256), 0,
-                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, b.d_seed, b.d_acc,
+                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
                                    1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
             b.d_head_cur = head_cur;
             first = false;
+            if (zmode == 1) {   // the centroids just moved: raise max_dist_color from the assignment of the last sweep
+                dim3 zg(maxh_z, b.nprob);
+#define LAUNCH_MAXDIST(CPV)                                                                                           \
+    do {                                                                                                              \
+        if (b.masked) hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_maxdist_kernel<CPV, true>), zg, dim3(256), 0, ctx->stream, b.d_probs, \
+                                         b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label);                   \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_maxdist_kernel<CPV, false>), zg, dim3(256), 0, ctx->stream, b.d_probs, \
+                                b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label);                            \
+    } while (0)
+                switch (b.CP) {
+                    case 4: LAUNCH_MAXDIST(4); break;
+                    case 8: LAUNCH_MAXDIST(8); break;
+                    case 12: LAUNCH_MAXDIST(12); break;
+                    default: LAUNCH_MAXDIST(16); break;
+                }
+#undef LAUNCH_MAXDIST
+            }
             // the update after the very last sweep is never read: skip its accumulation
             const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
             const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;

@@ -277,6 +277,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.start_label = 1;
     b.max_iter = S.sp.max_num_iter;
     b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
+    b.slic_zero = S.sp.slic_zero != 0;
     long long off = 0, maxpix = 1;
     b.probs.resize(np);
     b.windows.resize(np);
@@ -365,7 +366,6 @@ static int tiler_check(const float *img, int H, int W, int C, int Hg, int row0, 
     if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels: shard it across GPUs"); return OBIA_E_INVALID; }
     if (tp->tile_size <= 0 || tp->buffer < 0) { set_error("tile_size must be positive and buffer non-negative"); return OBIA_E_INVALID; }
     if (!(sp->compactness > 0.0) || sp->max_num_iter < 0) { set_error("bad SLIC parameters"); return OBIA_E_INVALID; }
-    if (sp->slic_zero) { set_error("slic_zero=True is not implemented in this version"); return OBIA_E_UNSUPPORTED; }
     if (!sp->enforce_connectivity) { set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)"); return OBIA_E_UNSUPPORTED; }
     if (sp->n_segments <= 0 && !(tp->crown_radius > 0.0 && tp->pixel_width > 0.0 && tp->pixel_height > 0.0)) {
         set_error("crown_radius and pixel size must be positive when n_segments is not given");

@@ -50,6 +50,8 @@ def kwargs_of(params):
               max_num_iter=params.get("max_iter", 10), convert2lab=params.get("convert2lab", None),
               min_size_factor=params.get("min_size_factor", 0.5), max_size_factor=params.get("max_size_factor", 3),
               start_label=params.get("start_label", 1))
+    if params.get("slic_zero"):
+        kw["slic_zero"] = True
     return kw
 
 
@@ -57,7 +59,7 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("name", [c for c in UNMASKED if "sliczero" not in c])
+@pytest.mark.parametrize("name", UNMASKED)
 def test_slic_pre_connectivity_vs_golden(amd, name):
     from obia_amd.segmentation import slic
     z, params = load(name)
@@ -71,7 +73,7 @@ def test_slic_pre_connectivity_vs_golden(amd, name):
     assert dis <= tol, f"{name}: {dis:.2e} of pixels differ before connectivity"
 
 
-@pytest.mark.parametrize("name", [c for c in UNMASKED if "sliczero" not in c])
+@pytest.mark.parametrize("name", UNMASKED)
 def test_slic_final_vs_golden(amd, name):
     from obia_amd.segmentation import slic
     z, params = load(name)
@@ -228,10 +230,6 @@ def test_zonal_stats_edge_cases(amd):
 def test_known_answer_block_images(amd, case):
     from obia_amd.segmentation import slic
     name, img, kw, expected, n_unique = case
-    if kw.get("slic_zero"):
-        with pytest.raises(NotImplementedError):
-            slic(img, **kw)
-        return
     seg = slic(img, **kw)
     sc.check_expected(seg, expected, n_unique)
 
