@@ -439,10 +439,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         STAMP(2)   // scoring
         STAMP_COUNT(0, 1)   // footprints
         // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
-        unsigned maxbest = 0x7f800000u;   // +inf
+        // a lane's largest current best distance (+inf while one of its valid pixels is unassigned, -inf when it has no
+        // valid pixel): the walk stops when lb exceeds it in every lane -- one compare and a ballot, no wave reduction
+        float mybest = fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3]));
         for (;;) {
             const unsigned mn = wave_umin(min(lbv[0], lbv[1]));
-            if (mn == 0xffffffffu || mn > maxbest) break;   // equality must still be visited: it can tie on k
+            if (mn == 0xffffffffu || !__ballot(__uint_as_float(mn) <= mybest)) break;   // equality must still be visited: it can tie on k
             int c;
             {
                 const unsigned long long b0 = __ballot(lbv[0] == mn);
@@ -528,13 +530,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     }
                 }
             }
-            // largest best distance in the wave (+inf while a valid pixel is unassigned; invalid pixels hold -inf);
-            // it can only have moved if some lane improved
-            if (__ballot(improved)) {
-                STAMP_COUNT(3, 1)   // visits that improved a pixel
-                const float lm = fmaxf(fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3])), 0.0f);
-                maxbest = wave_umax(__float_as_uint(lm));
-            }
+            if (improved) mybest = fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3]));
         }
         STAMP(3)   // visits
         int best_k[PPT];
