@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                                           (unsigned long long)x, one, fscale);
                 }
             } else {
-                labels[pix] = (best_s[j] >= 0) ? (best_k[j] - P.cent_off + start_label) : (start_label - 1);
+                __builtin_nontemporal_store((best_s[j] >= 0) ? (best_k[j] - P.cent_off + start_label) : (start_label - 1), &labels[pix]);
             }
         }
         STAMP(4)   // labels
