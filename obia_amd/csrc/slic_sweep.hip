@@ -404,9 +404,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         if (bxi > 0) fetch(fx0);
         // best_d of an invalid pixel is -inf: nothing is ever smaller, so the visits need no `valid` test
         float best_d[PPT], fyv[PPT];
-        int best_s[PPT];
+        int best_s[PPT], best_k[PPT];   // LDS slot and global index of the best candidate so far
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) { best_d[j] = valid[j] ? INFINITY : -INFINITY; best_s[j] = -1; fyv[j] = (float)(yb + j); }
+        for (int j = 0; j < PPT; ++j) { best_d[j] = valid[j] ? INFINITY : -INFINITY; best_s[j] = -1; best_k[j] = -1; fyv[j] = (float)(yb + j); }
 
         // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
         // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
@@ -519,13 +519,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     improved |= lt;
                     best_d[j] = lt ? dv[j] : best_d[j];
                     best_s[j] = lt ? c : best_s[j];
+                    best_k[j] = lt ? kk : best_k[j];
                 }
                 if (tie) {
 #pragma unroll
                     for (int j = 0; j < PPT; ++j) {
                         if (cand[j] && dv[j] == best_d[j] && best_s[j] != c && dv[j] < INFINITY) {   // `inf > inf` never assigns
-                            const int bk = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : 0x7fffffff;
-                            if (kk < bk) best_s[j] = c;
+                            if (best_s[j] < 0 || kk < best_k[j]) { best_s[j] = c; best_k[j] = kk; }
                         }
                     }
                 }
@@ -533,9 +533,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             if (improved) mybest = fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3]));
         }
         STAMP(3)   // visits
-        int best_k[PPT];
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) best_k[j] = best_s[j] >= 0 ? __float_as_int(s_hdr[best_s[j]][6]) : -1;
 
         // ---- labels ---------------------------------------------------------------------------------------------------
         int pk[PPT];   // accumulation key: LDS slot, or -1
