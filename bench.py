@@ -212,7 +212,7 @@ def main():
             "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,
                        "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
                        "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu"},
-            "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false>",
+            "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3
