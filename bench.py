@@ -8,9 +8,11 @@ One "step" = that whole pipeline once, input already resident in HBM.  value = H
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu]
 For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); every rank owns one
-4096-row slab of a (N*4096) x 32768 x 8 raster -- at N = 8 that is BASELINE configs[3] (32768^2) -- and the
-slabs are segmented as ONE raster: halo rows and seam label rows travel by send/recv between neighbouring ranks
-(obia_amd/distributed.py), no collective on the data path.  Fixed work per GPU => "scaling": "weak".
+16384-row slab (the N = 1 workload) of a (N*16384) x 16384 x 8 raster, and the slabs are segmented as ONE raster:
+halo rows and seam label rows travel by send/recv between neighbouring ranks (obia_amd/distributed.py), no collective
+on the data path.  The work per GPU is the same at every N, the N = 1 case included => "scaling": "weak".
+(White tile rows run in two parity classes there -- the order that lets neighbouring slabs work at the same time --
+so a rank segments four tile rows per batch instead of one.)
 
 The JSON line carries `roofline` (dominant kernel = the SLIC colour sweep slic_assign_kernel<8,true,false>:
 algorithmic bytes (4*C + 4 = 36 B/pixel) x pixels per launch / launch time from HIP events on
@@ -115,10 +117,10 @@ def main():
         workload = f"{H}x{W}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[2])"
         row0 = 0
     else:
-        W = 32768
-        H = 32768 // 8          # one slab of BASELINE configs[3] per GPU: fixed work per GPU
+        W = args.size
+        H = args.size           # every GPU gets a slab of the size of the N = 1 raster: fixed work per GPU
         row0 = rank * H
-        workload = (f"{world * H}x{W}x{C} raster sharded over {world} GPUs ({H}-row slab per GPU; BASELINE configs[3] at 8), "
+        workload = (f"{world * H}x{W}x{C} raster sharded over {world} GPUs ({H}-row slab per GPU = the N = 1 workload), "
                     f"tile={args.tile}, overlap={args.buffer}, seam exchange over RCCL send/recv")
     img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
     mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
