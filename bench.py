@@ -122,8 +122,18 @@ def main():
         row0 = rank * H
         workload = (f"{world * H}x{W}x{C} raster sharded over {world} GPUs ({H}-row slab per GPU = the N = 1 workload), "
                     f"tile={args.tile}, overlap={args.buffer}, seam exchange over RCCL send/recv")
-    img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
-    mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
+    if world == 1:
+        img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
+        mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
+        ext_img = ext_mask = None
+    else:
+        # the slab lives in the middle of rasters that have room for the neighbours' halo rows: the sharded driver then
+        # copies nothing per call
+        top, bot = ShardedTiler.halo_rows(rank, world, args.buffer)
+        ext_img = torch.empty((top + H + bot, W, C), dtype=torch.float32, device=dev)
+        ext_img[top:top + H] = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
+        ext_mask = torch.ones((top + H + bot, W), dtype=torch.uint8, device=dev)
+        img, mask = ext_img[top:top + H], ext_mask[top:top + H]
     ctx = _lib.Context(gpu)
     ctx.set_profiling(True)
     kw = dict(tile_size=args.tile, buffer=args.buffer, crown_radius=5, pixel_size=(0.5, 0.5), compactness=args.compactness, ctx=ctx)
@@ -135,12 +145,12 @@ def main():
             st = zonal_stats(img, lab, n_labels=n, ctx=ctx)
         else:
             t = ShardedTiler(img, mask, world * H, H // args.tile, args.tile, args.buffer, 5, (0.5, 0.5), ctx=ctx,
-                             compactness=args.compactness)
+                             ext_image=ext_img, ext_mask=ext_mask, compactness=args.compactness)
             lab, n = t.run()
-            ext_img, dense, n_owned = t.owned_labels()
+            halo_img, dense, n_owned = t.owned_labels()
             t.close()
             t_seg = ctx.timing()
-            st = zonal_stats(ext_img, dense, n_labels=n_owned, ctx=ctx)   # every segment counted once, by its owner
+            st = zonal_stats(halo_img, dense, n_labels=n_owned, ctx=ctx)   # every segment counted once, by its owner
         t_z = ctx.timing()
         return lab, n, st, t_seg, t_z
 

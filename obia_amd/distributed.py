@@ -99,8 +99,15 @@ def _p2p(ops):
 class ShardedTiler:
     """One rank of the sharded driver.  ``slab`` / ``mask_slab``: this rank's rows (whole tile rows)."""
 
+    @staticmethod
+    def halo_rows(rank, world, buffer):
+        """(rows above, rows below) a rank keeps of its neighbours: buffer + 1 towards every neighbour."""
+        hb = int(buffer) + 1
+        return (hb if rank > 0 else 0, hb if rank < world - 1 else 0)
+
     def __init__(self, slab, mask_slab, global_rows, tile_rows_per_rank, tile_size, buffer, crown_radius=5,
-                 pixel_size=(1.0, 1.0), engine_factory=None, group=None, ctx=None, **slic_kwargs):
+                 pixel_size=(1.0, 1.0), engine_factory=None, group=None, ctx=None, ext_image=None, ext_mask=None,
+                 **slic_kwargs):
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world > 127:
@@ -122,10 +129,27 @@ class ShardedTiler:
         if mask_slab is None:
             mask_slab = torch.ones((Hs, W), dtype=torch.uint8, device=self.dev)
         mask_slab = _lib.mask_bytes(mask_slab, self.dev)
-        ext = torch.empty((self.top + Hs + self.bot, W, slab.shape[2]), dtype=torch.float32, device=self.dev)
-        mext = torch.empty((self.top + Hs + self.bot, W), dtype=torch.uint8, device=self.dev)
-        ext[self.top:self.top + Hs] = slab
-        mext[self.top:self.top + Hs] = mask_slab
+        # `slab` / `mask_slab` may be the middle rows of caller-allocated rasters that already have room for the halo rows
+        # (ext_image / ext_mask, see halo_rows()): then nothing is copied.  A lone rank has no halo at all.
+        He = self.top + Hs + self.bot
+        if ext_image is not None:
+            if tuple(ext_image.shape) != (He, W, slab.shape[2]) or ext_image.dtype != torch.float32 or not ext_image.is_contiguous():
+                raise ValueError("ext_image must be a contiguous float32 (top + rows + bottom, W, C) tensor")
+            ext = ext_image
+        elif He == Hs and slab.dtype == torch.float32 and slab.is_contiguous():
+            ext = slab
+        else:
+            ext = torch.empty((He, W, slab.shape[2]), dtype=torch.float32, device=self.dev)
+            ext[self.top:self.top + Hs] = slab
+        if ext_mask is not None:
+            if tuple(ext_mask.shape) != (He, W) or ext_mask.dtype != torch.uint8 or not ext_mask.is_contiguous():
+                raise ValueError("ext_mask must be a contiguous uint8 (top + rows + bottom, W) tensor")
+            mext = ext_mask
+        elif He == Hs and mask_slab.is_contiguous():
+            mext = mask_slab
+        else:
+            mext = torch.empty((He, W), dtype=torch.uint8, device=self.dev)
+            mext[self.top:self.top + Hs] = mask_slab
         self._exchange_rows(ext, send_top=slab[:self.hb], send_bot=slab[Hs - self.hb:])
         self._exchange_rows(mext, send_top=mask_slab[:self.hb], send_bot=mask_slab[Hs - self.hb:])
         self.Hs, self.W = Hs, W

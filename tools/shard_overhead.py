@@ -8,7 +8,7 @@ from bench import synth_raster
 from obia_amd import _lib
 from obia_amd.tiling import create_tiled_segments
 from obia_amd.distributed import ShardedTiler
-H, W, C = 4096, 32768, 8
+H = W = int(os.environ.get("SIZE", 16384)); C = 8
 img = synth_raster(H, W, C, 0, torch.device("cuda"))
 mask = torch.ones((H, W), dtype=torch.uint8, device="cuda")
 ctx = _lib.Context(0)
@@ -16,7 +16,7 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.time()
     lab, n = create_tiled_segments(img, input_mask=mask, tile_size=2048, buffer=64, crown_radius=5, pixel_size=(0.5, 0.5), white_order="parity", ctx=ctx)
     torch.cuda.synchronize(); t1 = time.time()
-    t = ShardedTiler(img, mask, H, 2, 2048, 64, 5, (0.5, 0.5), ctx=ctx, compactness=10.0)
+    t = ShardedTiler(img, mask, H, H // 2048, 2048, 64, 5, (0.5, 0.5), ctx=ctx, compactness=10.0)
     torch.cuda.synchronize(); t2 = time.time()
     lab2, n2 = t.run()
     torch.cuda.synchronize(); t3 = time.time()
