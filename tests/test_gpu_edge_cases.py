@@ -162,3 +162,44 @@ def test_zonal_band_subsets_nans_and_crowded_tiles(oracle, C, bands, block):
     np.testing.assert_allclose(st["variance"], chk["variance"], rtol=1e-5, atol=1e-6 * 4050.0 ** 2, equal_nan=True)
     np.testing.assert_array_equal(st["min"], chk["min"].astype(np.float32))
     np.testing.assert_array_equal(st["max"], chk["max"].astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 37), (41, 1), (2, 3), (64, 64), (65, 129)])
+def test_widened_rows_on_degenerate_rasters(oracle, shape):
+    """polygon rings, edges, skewness / kurtosis and GLCM texture on rasters of one pixel, one row, one column, exactly
+    one tile and one tile plus a bit: same answers as the CPU restatements, no out-of-range access."""
+    from obia_amd.polygons import polygonize
+    from obia_amd.consumers import slic_edge
+    from obia_amd.statistics import zonal_stats, texture_stats, TEXTURE_PROPS
+    from oracle.polygons import label_rings
+    from oracle.consumers import edge_raster
+    from oracle import glcm
+    H, W = shape
+    rs = np.random.RandomState(H * 131 + W)
+    lab = rs.randint(0, 4, (H, W)).astype(np.int32)            # 0 = unlabelled
+    raw = rs.uniform(0, 100, (H, W, 3)).astype(np.float32)
+    tab = polygonize(lab, start_label=1)
+    got = [(int(tab.ring_label[r]), bool(tab.ring_is_hole[r]),
+            [(int(x), int(y)) for x, y in tab.xy[tab.ring_offset[r]:tab.ring_offset[r + 1]]]) for r in range(len(tab.ring_label))]
+    rings = label_rings(lab, start_label=1)
+    order = sorted(range(len(rings)), key=lambda i: (rings[i][0], rings[i][1], i))
+    assert got == [rings[i] for i in order]
+    np.testing.assert_array_equal(slic_edge(lab), edge_raster(lab).astype(np.float32))
+    if lab.max() >= 1:
+        st = zonal_stats(raw, lab, moments=True)
+        chk = oracle.zonal_stats_numpy(raw, lab)
+        assert np.array_equal(st["count"], chk["count"])
+        np.testing.assert_allclose(st["skewness"], chk["skewness"], rtol=1e-3, atol=1e-3, equal_nan=True)
+        tx = texture_stats(raw, lab)
+        ref = glcm.texture_stats(raw, lab)
+        for p in TEXTURE_PROPS:
+            np.testing.assert_allclose(tx[p], ref[p], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=p)
+
+
+def test_widened_rows_without_any_label():
+    from obia_amd.polygons import polygonize
+    from obia_amd.consumers import slic_edge
+    lab = np.zeros((20, 30), np.int32)
+    tab = polygonize(lab, start_label=1)
+    assert len(tab) == 0 and len(tab.ring_label) == 0 and tab.geojson_features() == []
+    assert not slic_edge(lab).any()
