@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     // wave max -> one atomic per wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
-    if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits, __float_as_uint(local_max));
+    if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits + p, __float_as_uint(local_max));   // one word per window
 }
 
 __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
@@ -260,60 +260,55 @@ __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
     if (i < ntot) keys[i] = (i < nkeys && (i & 1) == 0) ? 0xffffffffu : 0u;
 }
 
-int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
-                          int to_lab, float ratio, std::vector<int> *skip) {
-    (void)Hs;
-    ScopedSpan span(ctx, T_FEAT);
-    const int C = b.C, np = b.nprob;
+// Launch half of the feature pass on `stream`: min / max of every band of every window, then the features.
+// d_keys layout for np windows: keys[np][C][2] (min, max as ordered uints) | nonfinite[np] | max|feature| bits [np].
+int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys) {
     if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
-    // layout: keys[np][C][2] | nonfinite[np] | maxabs bits
-    const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + np + 1;
-    unsigned *d_keys = ctx->arena.get<unsigned>(ntot);
-    if (!d_keys) return OBIA_E_NOMEM;
+    const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + 2 * (size_t)np;
     unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
-    std::vector<unsigned> host(ntot);
     // (min, max) key pairs start at (0xffffffff, 0), the flags at 0: initialised on the device, no host round trip
-    hipLaunchKernelGGL(keys_init_kernel, dim3(cdiv((long long)ntot, 256)), dim3(256), 0, ctx->stream, d_keys, (int)nkeys, (int)ntot);
-    int maxh = 1;
-    long long maxpix = 1;
-    for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; long long n = (long long)w.h * w.w; if (n > maxpix) maxpix = n; }
+    hipLaunchKernelGGL(keys_init_kernel, dim3(cdiv((long long)ntot, 256)), dim3(256), 0, stream, d_keys, (int)nkeys, (int)ntot);
     if (normalize) {
         int gx = maxh < 2048 ? maxh : 2048;
         // float4 reads need 16-byte aligned rows: C % 4 == 0 and an aligned base pointer
         if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<4>), dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C,
-                               b.d_windows, d_keys, (int *)d_nonfinite);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<4>), dim3(gx, np), dim3(FP_NT), 0, stream, src, Ws, C, d_windows,
+                               d_keys, (int *)d_nonfinite);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<1>), dim3(gx, np), dim3(FP_NT), 0, ctx->stream, src, Ws, C,
-                               b.d_windows, d_keys, (int *)d_nonfinite);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<1>), dim3(gx, np), dim3(FP_NT), 0, stream, src, Ws, C, d_windows,
+                               d_keys, (int *)d_nonfinite);
     }
-    {
-        (void)maxpix;
-        dim3 grid(maxh < 4096 ? maxh : 4096, np);
-#define LAUNCH_FEAT(CPV)                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, ctx->stream, src, Ws, C,    \
-                       b.d_windows, d_keys, normalize, to_lab, ratio, b.d_feat, d_maxabs)
-        switch (b.CP) {
-            case 4: LAUNCH_FEAT(4); break;
-            case 8: LAUNCH_FEAT(8); break;
-            case 12: LAUNCH_FEAT(12); break;
-            case 16: LAUNCH_FEAT(16); break;
-            default: set_error("bad CP %d", b.CP); return OBIA_E_INVALID;
-        }
+    dim3 grid(maxh < 4096 ? maxh : 4096, np);
+#define LAUNCH_FEAT(CPV)                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, d_windows, d_keys,   \
+                       normalize, to_lab, ratio, d_feat, d_maxabs)
+    switch (CP) {
+        case 4: LAUNCH_FEAT(4); break;
+        case 8: LAUNCH_FEAT(8); break;
+        case 12: LAUNCH_FEAT(12); break;
+        case 16: LAUNCH_FEAT(16); break;
+        default: set_error("bad CP %d", CP); return OBIA_E_INVALID;
+    }
 #undef LAUNCH_FEAT
-    }
     OBIA_HIP_TRY(hipGetLastError());
-    // one read-back: min/max keys (constant-band check), non-finite flags, max|feature|
-    OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));
+    return OBIA_OK;
+}
+
+// Host half: constant / non-finite bands (-> skip flags or an error) and the fixed-point scale of the batch.  `keys`,
+// `nonfinite`, `maxabs` point at the read-back entries of the batch's FIRST window (np consecutive windows).
+int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *nonfinite, const unsigned *maxabs_bits, int normalize,
+                         std::vector<int> *skip) {
+    const int C = b.C, np = b.nprob;
     auto k2f = [](unsigned k) { unsigned bb = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &bb, 4); return f; };
     if (skip) skip->assign(np, 0);
     if (normalize) {
         for (int p = 0; p < np; ++p) {
-            bool bad = host[nkeys + p] != 0;
+            bool bad = nonfinite[p] != 0;
             int cb = -1;
             float cv = 0;
             for (int c = 0; c < C && !bad; ++c) {
-                float mn = k2f(host[((size_t)p * C + c) * 2]), mx = k2f(host[((size_t)p * C + c) * 2 + 1]);
+                float mn = k2f(keys[((size_t)p * C + c) * 2]), mx = k2f(keys[((size_t)p * C + c) * 2 + 1]);
                 if (!(mx > mn)) { cb = c; cv = mn; }
             }
             if (bad || cb >= 0) {
@@ -325,8 +320,12 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
             }
         }
     }
-    float maxabs; unsigned mb = host[nkeys + np]; memcpy(&maxabs, &mb, 4);
-    if (!(maxabs <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
+    float maxabs = 0.0f;
+    for (int p = 0; p < np; ++p) {
+        float v; memcpy(&v, &maxabs_bits[p], 4);
+        if (!(v <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
+        if (v > maxabs) maxabs = v;
+    }
     // fixed-point scale for the colour sums: totals |feature| * maxcount * 2^s < 2^62, and every partial that is
     // converted (at most one 128x64 tile of pixels) stays below 2^50 (to_fixed in slic_sweep.hip needs < 2^51)
     long long maxcount = 1;
@@ -339,6 +338,23 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     if (s < -60) s = -60;
     b.fscale = std::ldexp(1.0, s);
     return OBIA_OK;
+}
+
+int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
+                          int to_lab, float ratio, std::vector<int> *skip) {
+    (void)Hs;
+    ScopedSpan span(ctx, T_FEAT);
+    const int C = b.C, np = b.nprob;
+    const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + 2 * (size_t)np;
+    unsigned *d_keys = ctx->arena.get<unsigned>(ntot);
+    if (!d_keys) return OBIA_E_NOMEM;
+    int maxh = 1;
+    for (auto &w : b.windows) if (w.h > maxh) maxh = w.h;
+    OBIA_TRY(slic_features_launch(ctx->stream, C, b.CP, np, b.d_windows, maxh, src, Ws, normalize, to_lab, ratio, b.d_feat, d_keys));
+    // one read-back: min/max keys (constant-band check), non-finite flags, max|feature| per window
+    std::vector<unsigned> host(ntot);
+    OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));
+    return slic_features_finish(b, host.data(), host.data() + nkeys, host.data() + nkeys + np, normalize, skip);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -71,6 +71,10 @@ struct SlicBatch {
 // `skip` (nullable): when given, a problem whose window holds a constant or non-finite band is flagged
 // skip[p] = 1 (its features are zero) instead of failing the whole batch -- the reference's tiler
 // swallows the per-tile ValueError (tiling.py:149-150).
+int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys);
+int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *nonfinite, const unsigned *maxabs_bits, int normalize,
+                         std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
                           int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
 

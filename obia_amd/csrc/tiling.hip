@@ -255,6 +255,20 @@ struct TileState {
     int clx, cly;          // corner square (pixels)
     obia_tiling_params tp;
     obia_slic_params sp;
+    // features of ALL white tiles, prepared in one batch (they depend on the raster only): windows in processing order,
+    // one dense buffer, keys read back once before the white pass
+    struct PreFeat {
+        bool ready = false;
+        std::vector<TileWin> wins;
+        std::vector<SrcWindow> windows;
+        std::vector<unsigned> host;      // keys | nonfinite | max|feature| of all windows
+        float *d_feat = nullptr;
+        SrcWindow *d_windows = nullptr;
+        unsigned *d_keys = nullptr;
+        int maxh = 1;
+        bool launched = false;
+        size_t cursor = 0;               // next window to be consumed by a white batch
+    } pf;
 };
 
 static int grid_rows(const std::vector<TileWin> &wins) {   // row-walking kernels: one block per row (capped)
@@ -264,6 +278,8 @@ static int grid_rows(const std::vector<TileWin> &wins) {   // row-walking kernel
 }
 
 // One batch of tiles: mask -> features -> plan -> sweeps -> connectivity -> scatter.
+static int prefetch_white_launch(obia_ctx *ctx, TileState &S);
+
 static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &wins, bool white) {
     const int np = (int)wins.size();
     if (np == 0) return OBIA_OK;
@@ -296,7 +312,18 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     TileWin *d_wins = A.get<TileWin>(np);
     b.d_windows = A.get<SrcWindow>(np);
     b.d_mask = A.get<uint8_t>((size_t)off);
-    b.d_feat = A.get<float>((size_t)off * b.CP);
+    const bool pre = white && S.pf.ready;
+    if (pre) {
+        // this batch is the next np windows of the prefetched set (same order, same sizes: checked)
+        if (S.pf.cursor + np > S.pf.wins.size()) { set_error("white batch beyond the prefetched windows"); return OBIA_E_INVALID; }
+        for (int p = 0; p < np; ++p) {
+            const TileWin &a = S.pf.wins[S.pf.cursor + p];
+            if (a.y0 != wins[p].y0 || a.x0 != wins[p].x0 || a.h != wins[p].h || a.w != wins[p].w) { set_error("white batch does not match the prefetched windows"); return OBIA_E_INVALID; }
+        }
+        b.d_feat = S.pf.d_feat + (size_t)S.pf.windows[S.pf.cursor].pix_off * b.CP;
+    } else {
+        b.d_feat = A.get<float>((size_t)off * b.CP);
+    }
     b.d_labels = A.get<int32_t>((size_t)off);
     int32_t *d_final = A.get<int32_t>((size_t)off);
     if (!d_wins || !b.d_windows || !b.d_mask || !b.d_feat || !b.d_labels || !d_final) return OBIA_E_NOMEM;
@@ -312,7 +339,14 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
     std::vector<int> skip;
     const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
-    OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp.compactness), &skip));
+    if (pre) {
+        const size_t NP = S.pf.wins.size(), nkeys = NP * (size_t)S.C * 2;
+        const unsigned *h = S.pf.host.data();
+        OBIA_TRY(slic_features_finish(b, h + S.pf.cursor * (size_t)S.C * 2, h + nkeys + S.pf.cursor, h + nkeys + NP + S.pf.cursor, 1, &skip));
+        S.pf.cursor += np;
+    } else {
+        OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp.compactness), &skip));
+    }
     std::vector<int> nvalid;
     OBIA_TRY(slic_count_valid(ctx, b, nvalid));
     std::vector<int> nseg(np);
@@ -412,6 +446,79 @@ static int tiler_init(obia_ctx *ctx, TileState &S, const float *img, const uint8
     return OBIA_OK;
 }
 
+// window of the white tile (tj, ti): grown by `buffer`, clamped to the GLOBAL raster, in local rows
+static TileWin white_window(const TileState &S, int tj, int ti) {
+    const int T = S.tp.tile_size, B = S.tp.buffer;
+    const int y0 = std::max(0, tj * T - B), y1 = std::min(S.Hg, tj * T + T + B);
+    const int x0 = std::max(0, ti * T - B), x1 = std::min(S.W, ti * T + T + B);
+    return TileWin{y0 - S.row0, x0, y1 - y0, x1 - x0, 0, std::min(S.cly, y1 - y0), std::min(S.clx, x1 - x0)};
+}
+
+// The feature pass of ALL white tiles runs as ONE batch before the white rows (it depends on the raster only), in the
+// order in which the white batches will consume the windows: one large launch instead of one per tile row, one read-back
+// instead of eight.  plan: windows and buffers (allocated before any batch scope of the arena); launch; fetch: the keys.
+// (Running it on a second stream beside the black sweeps was measured: the HBM-bound pass and the VALU-bound sweeps slow
+// each other down by more than the overlap gains -- 66.5 vs 63.2 ms per step -- so it stays on the main stream.)
+static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
+    const int T = S.tp.tile_size;
+    const int ntx = cdiv(S.W, T), nty = cdiv(S.Hg, T);
+    TileState::PreFeat &pf = S.pf;
+    pf = TileState::PreFeat();
+    for (int cls = 0; cls < (white_order == 1 ? 2 : 1); ++cls)
+        for (int tj = 0; tj < nty; ++tj) {
+            if (white_order == 1 && (tj & 1) != cls) continue;
+            for (int ti = 0; ti < ntx; ++ti) {
+                if ((ti + tj) % 2 == 0) continue;
+                const TileWin t = white_window(S, tj, ti);
+                if (t.h > 0 && t.w > 0) pf.wins.push_back(t);
+            }
+        }
+    const size_t NP = pf.wins.size();
+    if (NP == 0) return OBIA_OK;
+    long long off = 0;
+    pf.windows.resize(NP);
+    for (size_t p = 0; p < NP; ++p) {
+        const TileWin &t = pf.wins[p];
+        if (t.y0 < 0 || t.y0 + t.h > S.H) { pf = TileState::PreFeat(); return OBIA_OK; }   // the batches report the halo error
+        pf.windows[p] = SrcWindow{t.y0, t.x0, t.h, t.w, off};
+        off += (long long)t.h * t.w;
+        if (t.h > pf.maxh) pf.maxh = t.h;
+    }
+    const int CP = (S.C + 3) & ~3;
+    if ((double)off * CP * 4.0 > 32.0 * 1024 * 1024 * 1024) { pf = TileState::PreFeat(); return OBIA_OK; }   // too big to hold: per-batch features
+    Arena &A = ctx->arena;
+    const size_t ntot = NP * (size_t)S.C * 2 + 2 * NP;
+    pf.d_windows = A.get<SrcWindow>(NP);
+    pf.d_keys = A.get<unsigned>(ntot);
+    pf.d_feat = A.get<float>((size_t)off * CP);
+    if (!pf.d_windows || !pf.d_keys || !pf.d_feat) return OBIA_E_NOMEM;
+    pf.host.resize(ntot);
+    return OBIA_OK;
+}
+
+static int prefetch_white_launch(obia_ctx *ctx, TileState &S) {
+    TileState::PreFeat &pf = S.pf;
+    if (pf.launched || !pf.d_feat) return OBIA_OK;
+    pf.launched = true;
+    ScopedSpan span(ctx, T_FEAT);
+    const size_t NP = pf.wins.size();
+    const int CP = (S.C + 3) & ~3;
+    OBIA_HIP_TRY(hipMemcpyAsync(pf.d_windows, pf.windows.data(), sizeof(SrcWindow) * NP, hipMemcpyHostToDevice, ctx->stream));
+    const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
+    OBIA_TRY(slic_features_launch(ctx->stream, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
+                                  (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys));
+    return OBIA_OK;
+}
+
+static int prefetch_white_fetch(obia_ctx *ctx, TileState &S) {
+    if (!S.pf.d_feat) return OBIA_OK;
+    OBIA_TRY(prefetch_white_launch(ctx, S));
+    OBIA_TRY(read_back(ctx, S.pf.host.data(), S.pf.d_keys, S.pf.host.size() * sizeof(unsigned)));
+    S.pf.ready = true;
+    S.pf.cursor = 0;
+    return OBIA_OK;
+}
+
 // Tiles of GLOBAL tile rows [tr_lo, tr_hi) with (tr % 2 == parity) when parity is 0 or 1.  Black tiles: exact
 // windows, one batch for the whole range.  White tiles: windows grown by `buffer` and clamped to the GLOBAL
 // raster, one batch per tile-row (windows of one tile-row never overlap; those of adjacent rows overlap at
@@ -438,9 +545,7 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
                 TileWin t{tj * T - S.row0, ti * T, std::min(T, S.Hg - tj * T), std::min(T, S.W - ti * T), 0, 0, 0};
                 if (t.h > 0 && t.w > 0) wins.push_back(t);
             } else {
-                const int y0 = std::max(0, tj * T - B), y1 = std::min(S.Hg, tj * T + T + B);
-                const int x0 = std::max(0, ti * T - B), x1 = std::min(S.W, ti * T + T + B);
-                TileWin t{y0 - S.row0, x0, y1 - y0, x1 - x0, 0, std::min(S.cly, y1 - y0), std::min(S.clx, x1 - x0)};
+                const TileWin t = white_window(S, tj, ti);
                 if (t.h > 0 && t.w > 0) wins.push_back(t);
             }
         }
@@ -474,7 +579,9 @@ static int tiled_slic_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, 
     OBIA_TRY(tiler_init(ctx, S, img, mask, H, W, C, H, 0, tp, sp, labels_out, 0));
     OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * (size_t)H * W, ctx->stream));
     const int nty = cdiv(H, tp->tile_size);
+    OBIA_TRY(prefetch_white_plan(ctx, S, tp->white_order));               // features of all white tiles: one batch
     OBIA_TRY(tiler_run(ctx, S, false, 0, nty, -1));                       // pass 1: black tiles
+    OBIA_TRY(prefetch_white_fetch(ctx, S));
     if (tp->white_order == 1) {                                           // pass 2, two parity classes of tile rows
         OBIA_TRY(tiler_run(ctx, S, true, 0, nty, 0));
         OBIA_TRY(tiler_run(ctx, S, true, 0, nty, 1));
