@@ -48,3 +48,16 @@ def test_point_join_assigns_classes_and_reports_mixed_segments():
     r, c = 25.3, 41.8
     X = aff2[0] * c + aff2[1] * r + aff2[4]; Y = aff2[2] * c + aff2[3] * r + aff2[5]
     assert sample_labels(lab, aff2, [(X, Y)]).tolist() == [4]
+
+
+def test_quickstart_example_runs(tmp_path, monkeypatch):
+    """examples/quickstart.py: segment -> objects table -> polygons -> tiled driver -> consumers, end to end."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "quickstart.py")
+    spec = importlib.util.spec_from_file_location("quickstart_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
+    out = os.path.join(os.path.dirname(path), "quickstart_segments.geojson")
+    assert os.path.getsize(out) > 1000
