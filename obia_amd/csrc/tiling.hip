@@ -528,6 +528,9 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
     const int ntx = cdiv(S.W, T), nty = cdiv(S.Hg, T);
     if (tr_lo < 0) tr_lo = 0;
     if (tr_hi > nty) tr_hi = nty;
+    // white tile rows of ONE parity class do not see each other (their windows are T - 2B rows apart): the whole class is
+    // one batch; in raster order every row sees the corner overlaps of the row before it: one batch per row
+    const bool per_row = !(parity >= 0 && T > 2 * B);
     std::vector<TileWin> wins;
     auto flush = [&]() -> int {
         for (auto &t : wins)
@@ -549,9 +552,9 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
                 if (t.h > 0 && t.w > 0) wins.push_back(t);
             }
         }
-        if (white) OBIA_TRY(flush());
+        if (white && per_row) OBIA_TRY(flush());
     }
-    if (!white) OBIA_TRY(flush());
+    if (!wins.empty()) OBIA_TRY(flush());
     return OBIA_OK;
 }
 
