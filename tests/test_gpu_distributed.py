@@ -66,3 +66,19 @@ def test_two_ranks_on_one_gpu_equal_single_gpu(tmp_path):
     assert own[0][2] + own[1][2] == int((ref > 0).sum())                   # and every labelled pixel counted once
     assert np.array_equal(lab == 0, ref == 0)
     assert adjusted_rand_index(lab, ref) == 1.0
+
+
+def test_rccl_backend_wiring_with_one_rank():
+    """The sharded driver over torch.distributed's nccl backend (= RCCL) with a one-rank group on this GPU: process group
+    on a device, all_gather / all_reduce / barrier on device tensors, result identical to the one-GPU parity-order
+    driver.  (The multi-rank exchange itself is covered by the gloo tests; it needs several GPUs to run over RCCL.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_one_rank.py")], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("nccl one-rank ok")]
+    assert line and line[0].endswith("True"), out.stdout[-500:]
