@@ -47,6 +47,9 @@ __device__ unsigned long long g_stamp[16];
 constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
 constexpr int PPT = 4;          // pixels per lane (vertical strip)
+#ifndef LEAN_WAVES
+#define LEAN_WAVES 8
+#endif
 constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); 96 keeps 5 workgroups per CU
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
@@ -255,14 +258,17 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 }
 
 // K2: the sweep.  grid = (max tiles per problem, nprob).
-template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(
+// LEAN: a spatial-only pre-pass sweep that folds no colours (nine of the ten pre-pass sweeps): no feature registers, no
+// colour scratch in LDS -- the same code with those parts compiled out, launched at a higher occupancy.
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN>
+__device__ __forceinline__ void slic_assign_body(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
-    int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,
+    int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color_arg,
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter) {
+    const int accum_color = LEAN ? 0 : accum_color_arg;
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
     // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
@@ -277,8 +283,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
     __shared__ unsigned long long s_acc[MAXC][AQ];
-    __shared__ double s_tf[NT / 64][CP][65];    // 65: row stride that keeps the transposed reads conflict-free
-    __shared__ int s_tkey[NT / 64][64];
+    __shared__ double s_tf[LEAN ? 1 : NT / 64][LEAN ? 1 : CP][LEAN ? 1 : 65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ int s_tkey[LEAN ? 1 : NT / 64][LEAN ? 1 : 64];
     __shared__ int s_cnt, s_uncacheable;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const int fy1 = min(fy0 + FB, P.H);
     const int yb = fy0 + PPT * (lane >> 4);
     const bool want_feat = !IGNORE_COLOR || accum_color;
-    float f[PPT][CP];
+    float f[PPT][LEAN ? 1 : CP];
     bool valid[PPT];
     auto fetch = [&](int fx0) {
         const int xx = fx0 + (lane & 15);
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const long long pix = P.pix_off + (long long)y * P.W + xx;
             if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
             valid[j] = v;
-            if (v && want_feat) {
+            if (!LEAN && v && want_feat) {
                 const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
 #pragma unroll
                 for (int q = 0; q < CP / 4; ++q) {
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < CP; ++c) f[j][c] = 0.0f;
+                for (int c = 0; c < (LEAN ? 1 : CP); ++c) f[j][c] = 0.0f;
             }
         }
     };
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                         float dc = 0.0f;
 #pragma unroll
                         for (int ch = 0; ch < CP; ++ch) {
-                            const float t = f[j][ch] - col[ch];
+                            const float t = f[j][LEAN ? 0 : ch] - col[ch];
                             dc += t * t;
                         }
                         // SLIC-zero: the colour term is scaled by the largest colour distance seen in this cluster so far
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 if (prev >= start_label && accumulate) {
                     double one[CP];
 #pragma unroll
-                    for (int ch = 0; ch < CP; ++ch) one[ch] = (double)f[j][ch];
+                    for (int ch = 0; ch < CP; ++ch) one[ch] = LEAN ? 0.0 : (double)f[j][LEAN ? 0 : ch];
                     global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, 1u, (unsigned)y,
                                           (unsigned long long)x, one, fscale);
                 }
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // Colour part: per-lane runs of equal slot over the strip, summed in double (exact for 4 floats); the FIRST run
         // of every lane goes through the transposed fold below, later runs (a strip crossing a segment boundary) go
         // straight to the LDS accumulators.
-        if (accum_color) s_tkey[wv][lane] = -1;
+        if (!LEAN && accum_color) s_tkey[wv][lane] = -1;
         {
             const unsigned long long xrel = (unsigned long long)(x - tx0);
             int rkey = -1, nruns = 0;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             auto close_run = [&]() {
                 if (rkey < 0) return;
                 atomicAdd(&s_acc[rkey][CP], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
-                if (accum_color) {
+                if (!LEAN && accum_color) {
                     if (nruns == 0) {   // the lane's slot in the transposed scratch
                         s_tkey[wv][lane] = rkey;
 #pragma unroll
@@ -600,16 +606,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 }
                 if (pk[j] >= 0) {
                     rn += 1; ry += (unsigned)(yb + j - ty0);
-                    if (accum_color) {
+                    if (!LEAN && accum_color) {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][ch];
+                        for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][LEAN ? 0 : ch];
                     }
                 }
             }
             close_run();
         }
         STAMP(5)   // run merge
-        if (!accum_color) continue;   // wave-uniform: spatial-only pre-pass sweeps fold no colours
+        if (LEAN || !accum_color) continue;   // wave-uniform: spatial-only pre-pass sweeps fold no colours
         // transposed fold: lane (fld, g) folds the 8 strips 8g .. 8g+7 of colour field fld
         wave_lds_sync();
 #pragma unroll
@@ -660,6 +666,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     if (keep && tid == 0) { ck[0] = nc; tile_lp[tile_id] = sweep_id; }
     STAMP(7)   // barrier + flush
     STAMP_FLUSH
+}
+
+#define OBIA_ASSIGN_PARAMS                                                                                             \
+    const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,             \
+        const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,                      \
+        int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,      \
+        int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
+        int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
+        unsigned long long *__restrict__ px_counter
+#define OBIA_ASSIGN_ARGS                                                                                               \
+    probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, accum_color, start_label, fscale, bin_stamp, tile_lp, \
+        cache_k, cache_q, sweep_id, use_cache, px_counter
+
+// the colour sweeps and the last pre-pass sweep: 96 VGPRs, 27 KB of LDS, five waves per SIMD
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(OBIA_ASSIGN_PARAMS) {
+    slic_assign_body<CP, MASKED, IGNORE_COLOR, FIXPT, SLICZERO, false>(OBIA_ASSIGN_ARGS);
+}
+
+// the pre-pass sweeps that fold no colours: no feature registers, 10 KB of LDS, eight waves per SIMD
+template <int CP, bool MASKED, bool FIXPT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LEAN_WAVES, LEAN_WAVES))) void slic_prepass_kernel(OBIA_ASSIGN_PARAMS) {
+    slic_assign_body<CP, MASKED, true, FIXPT, false, true>(OBIA_ASSIGN_ARGS);
 }
 
 #ifdef OBIA_STAMP
@@ -719,9 +748,14 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
                        use_cache, px_counter)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
+#define LAUNCH_LEAN_(M, F)                                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
+                       b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, accum_color,           \
+                       b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
-        if (b.slic_zero && !(I)) LAUNCH_ASSIGN_(M, false, false, true);                                              \
+        if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \
+        else if (b.slic_zero && !(I)) LAUNCH_ASSIGN_(M, false, false, true);                                         \
         else if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true, false);                                                    \
         else LAUNCH_ASSIGN_(M, I, false, false);                                                                     \
     } while (0)
@@ -729,6 +763,7 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     else LAUNCH_ASSIGN(false, false);
 #undef LAUNCH_ASSIGN
 #undef LAUNCH_ASSIGN_
+#undef LAUNCH_LEAN_
 }
 
 __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
