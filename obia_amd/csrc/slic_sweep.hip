@@ -48,7 +48,7 @@ constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
 constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #ifndef LEAN_WAVES
-#define LEAN_WAVES 8
+#define LEAN_WAVES 7
 #endif
 constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); 96 keeps 5 workgroups per CU
 
