@@ -276,7 +276,8 @@ __device__ __forceinline__ void slic_assign_body(
     const int tile = blockIdx.x;
     if (tile >= P.tiles_x * P.tiles_y) return;
     constexpr int RS = CENT_REC + CP;
-    constexpr int AQ = CP + 1;                  // qwords of an LDS accumulator: colours, then one packed word
+    constexpr int AQ = LEAN ? 1 : CP + 1;       // qwords of an LDS accumulator: colours (not in the lean kernel), then one packed word
+    constexpr int PWI = LEAN ? 0 : CP;          // index of the packed word
                                                 //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 128x64 tile: n <= 8192,
                                                 //   sums <= 8192 * 127 < 2^20: no field can carry into the next)
     constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
@@ -583,7 +584,7 @@ __device__ __forceinline__ void slic_assign_body(
             for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
             auto close_run = [&]() {
                 if (rkey < 0) return;
-                atomicAdd(&s_acc[rkey][CP], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
+                atomicAdd(&s_acc[rkey][PWI], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
                 if (!LEAN && accum_color) {
                     if (nruns == 0) {   // the lane's slot in the transposed scratch
                         s_tkey[wv][lane] = rkey;
@@ -591,7 +592,7 @@ __device__ __forceinline__ void slic_assign_body(
                         for (int ch = 0; ch < CP; ++ch) s_tf[wv][ch][lane] = rf[ch];
                     } else {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][ch], to_fixed(rf[ch], fscale));
+                        for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][LEAN ? 0 : ch], to_fixed(rf[ch], fscale));
                     }
                 }
                 ++nruns;
@@ -630,12 +631,12 @@ __device__ __forceinline__ void slic_assign_body(
                     const int key = s_tkey[wv][src];
                     const double v = key >= 0 ? s_tf[wv][fld][src] : 0.0;   // strips without a run left stale data
                     if (key != cur) {
-                        if (cur >= 0) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
+                        if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], to_fixed(sum, fscale));
                         cur = key; sum = 0.0;
                     }
                     sum += v;
                 }
-                if (cur >= 0) atomicAdd(&s_acc[cur][fld], to_fixed(sum, fscale));
+                if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], to_fixed(sum, fscale));
             }
         }
         wave_lds_sync();   // the scratch is rewritten by the next footprint
@@ -648,15 +649,17 @@ __device__ __forceinline__ void slic_assign_body(
     const bool keep = FIXPT && !s_uncacheable;
     int *ck = keep ? cache_k + (size_t)tile_id * (MAXC + 1) : nullptr;
     unsigned long long *cq = keep ? cache_q + (size_t)tile_id * MAXC * GQ : nullptr;
-    for (int i = tid; i < nc * GQ; i += NT) {
-        const int slot = i / GQ, q = i - slot * GQ;
-        const unsigned long long pw = s_acc[slot][CP];
+    // (the lean kernel without the fixed-point cache only has the two integer words of every record to send)
+    constexpr int QLO = (LEAN && !FIXPT) ? CP : 0, QN = GQ - QLO;
+    for (int i = tid; i < nc * QN; i += NT) {
+        const int slot = i / QN, q = QLO + (i - slot * QN);
+        const unsigned long long pw = s_acc[slot][PWI];
         const unsigned long long n = pw & 0xffffull;
-        if (FIXPT && keep && q == 0) ck[1 + slot] = n ? __float_as_int(s_hdr[slot][6]) : -1;
+        if (FIXPT && keep && q == QLO) ck[1 + slot] = n ? __float_as_int(s_hdr[slot][6]) : -1;
         if (n == 0ull) continue;   // nothing landed on this centroid
         const int k = __float_as_int(s_hdr[slot][6]);
         unsigned long long v;
-        if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][q] : 0ull; }
+        if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][LEAN ? 0 : q] : 0ull; }
         else if (q == CP) v = n | ((((pw >> 16) & 0xffffffull) + n * (unsigned long long)ty0) << 32);
         else v = (pw >> 40) + n * (unsigned long long)tx0;
         if (FIXPT && keep) cq[(size_t)slot * GQ + q] = v;
