@@ -268,7 +268,10 @@ __device__ __forceinline__ void slic_assign_body(
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter) {
-    const int accum_color = LEAN ? 0 : accum_color_arg;
+    // colours are folded by every sweep that runs this body without LEAN (the colour sweeps and the last pre-pass sweep)
+    // and by none that runs it with LEAN: a compile-time constant either way
+    (void)accum_color_arg;
+    constexpr int accum_color = LEAN ? 0 : 1;
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
     // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
