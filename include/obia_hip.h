@@ -101,6 +101,26 @@ int obia_enforce_connectivity_i32_dev(obia_ctx *ctx, const int32_t *labels_in, i
                                       int min_size, int max_size, int start_label,
                                       int32_t *labels_out, int *n_labels_out);
 
+/* B1 with caller-supplied initial centroids instead of the library's seeding rule: the output of scikit-image's
+ * own `_get_mask_centroids(mask, n_segments)` (slic_superpixels.py:14-68: RandomState / kmeans2 / pdist -- RNG and
+ * version dependent, so the library does not restate it) or of `_get_grid_centroids` (:71-104).  Everything after
+ * the seeding is the reference's: `step = max(steps)` (:288), spatial-only pre-pass when a mask is given (:310-314),
+ * main pass, connectivity with segment_size = mask.sum() / n_centroids (:321-326).  This is how the maskSLIC path
+ * every tile of create_tiled_segments takes (tiling.py:121-143) is pinned on scikit-image output.
+ *   seeds->yx        HOST pointer, n x (y, x) float64 centroid positions in pixel coordinates
+ *   seeds->steps_zyx the `steps` array returned with them (depth axis first; 1.0 for a 2-D image)
+ *   params->n_segments is not used for seeding (K = seeds->n)
+ *   stage 0: final labels (n_out = number of labels); 1: labels before connectivity (n_out = K).               */
+typedef struct obia_slic_seeds {
+    const double *yx;
+    double steps_zyx[3];
+    int32_t n;
+    int32_t reserved;
+} obia_slic_seeds;
+int obia_slic_seeded_f32_dev(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, const uint8_t *mask,
+                             const obia_slic_params *params, const obia_slic_seeds *seeds, int stage,
+                             int32_t *labels_out, int *n_out);
+
 /* ---- B2: zonal-statistics operator ----------------------------------------------------------------
  * Replaces the per-segment loop crop_image_to_bbox -> mask_image_with_polygon ->
  * calculate_spectral_stats (segment_statistics.py:475-491, :143-172; utils/utils.py:37-67), batched

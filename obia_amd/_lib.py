@@ -25,6 +25,12 @@ class SlicParams(ctypes.Structure):
                 ("exit_on_fixed_point", ctypes.c_int32)]
 
 
+class SlicSeeds(ctypes.Structure):
+    """obia_slic_seeds (include/obia_hip.h): caller-supplied initial centroids."""
+    _fields_ = [("yx", ctypes.c_void_p), ("steps_zyx", ctypes.c_double * 3), ("n", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class TilingParams(ctypes.Structure):
     """obia_tiling_params (include/obia_hip.h)."""
     _fields_ = [("crown_radius", ctypes.c_double), ("pixel_width", ctypes.c_double),
@@ -46,6 +52,8 @@ _SIGNATURES = {
     "obia_slic_f32": (_I, [_P, _P, _I, _I, _I, _P, ctypes.POINTER(SlicParams), _P, ctypes.POINTER(_I)]),
     "obia_slic_f32_dev": (_I, [_P, _P, _I, _I, _I, _P, ctypes.POINTER(SlicParams), _P, ctypes.POINTER(_I)]),
     "obia_slic_assign_only_f32_dev": (_I, [_P, _P, _I, _I, _I, _P, ctypes.POINTER(SlicParams), _P, ctypes.POINTER(_I)]),
+    "obia_slic_seeded_f32_dev": (_I, [_P, _P, _I, _I, _I, _P, ctypes.POINTER(SlicParams), ctypes.POINTER(SlicSeeds), _I, _P,
+                                      ctypes.POINTER(_I)]),
     "obia_enforce_connectivity_i32_dev": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, ctypes.POINTER(_I)]),
     "obia_zonal_stats_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "obia_zonal_stats_f32_dev": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -29,7 +29,7 @@ int check_slic_args(const float *img, int H, int W, int C, const obia_slic_param
 
 // Whole-raster SLIC up to the pre-connectivity labels (device pointers).  On return b holds the plan.
 int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
-                const obia_slic_params *p, SlicBatch &b) {
+                const obia_slic_params *p, SlicBatch &b, const ExternalSeeds *ext = nullptr) {
     Arena &A = ctx->arena;
     b.nprob = 1;
     b.C = C;
@@ -54,7 +54,7 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     const float ratio = (float)(1.0 / p->compactness);   // `image * ratio`: float32 array times Python float
     OBIA_TRY(slic_prepare_features(ctx, b, img, H, W, p->normalize_bands, to_lab, ratio));
     std::vector<int> nseg(1, p->n_segments);
-    OBIA_TRY(slic_plan_and_seed(ctx, b, nseg));
+    OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, nullptr, ext));
     if (b.probs[0].K <= 0) {
         set_error("mask is empty: nothing to segment");
         return OBIA_E_EMPTY;
@@ -67,8 +67,27 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
 
 extern "C" {
 
-int obia_slic_assign_only_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
-                                  const obia_slic_params *params, int32_t *labels_pre_out, int *n_centroids_out) {
+static int check_seeds(const obia_slic_seeds *seeds, int H, int W, ExternalSeeds &ext) {
+    if (!seeds) { set_error("null seeds"); return OBIA_E_INVALID; }
+    if (!seeds->yx || seeds->n < 1) { set_error("seeds: need at least one (y, x) pair"); return OBIA_E_INVALID; }
+    for (int i = 0; i < seeds->n; ++i) {
+        const double y = seeds->yx[2 * (size_t)i], x = seeds->yx[2 * (size_t)i + 1];
+        if (!(y >= 0.0 && y <= (double)(H - 1) && x >= 0.0 && x <= (double)(W - 1))) {
+            set_error("seed %d = (%g, %g) lies outside the (%d, %d) raster", i, y, x, H, W);
+            return OBIA_E_INVALID;
+        }
+    }
+    double st = seeds->steps_zyx[0];
+    if (seeds->steps_zyx[1] > st) st = seeds->steps_zyx[1];
+    if (seeds->steps_zyx[2] > st) st = seeds->steps_zyx[2];
+    if (!(st > 0.0) || !(st < 1e9)) { set_error("seeds: steps must be positive and finite"); return OBIA_E_INVALID; }
+    ext.yx = seeds->yx; ext.n = seeds->n; ext.step = st;   // step = max(steps), slic_superpixels.py:288
+    return OBIA_OK;
+}
+
+static int slic_assign_only_impl(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                                 const obia_slic_params *params, const ExternalSeeds *ext, int32_t *labels_pre_out,
+                                 int *n_centroids_out) {
     OBIA_TRY(check_ctx(ctx));
     OBIA_TRY(check_slic_args(img, H, W, C, params));
     if (!labels_pre_out) { set_error("null output"); return OBIA_E_INVALID; }
@@ -78,7 +97,7 @@ int obia_slic_assign_only_f32_dev(obia_ctx *ctx, const float *img, int H, int W,
     int rc;
     {
         ScopedSpan total(ctx, T_TOTAL);
-        rc = slic_single(ctx, img, H, W, C, mask, params, b);
+        rc = slic_single(ctx, img, H, W, C, mask, params, b, ext);
         if (rc == OBIA_OK) {
             hipError_t e = hipMemcpyAsync(labels_pre_out, b.d_labels, sizeof(int32_t) * (size_t)H * W, hipMemcpyDeviceToDevice, ctx->stream);
             if (e != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(e)); rc = OBIA_E_HIP; }
@@ -91,8 +110,8 @@ int obia_slic_assign_only_f32_dev(obia_ctx *ctx, const float *img, int H, int W,
     return OBIA_OK;
 }
 
-int obia_slic_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
-                      const obia_slic_params *params, int32_t *labels_out, int *n_labels_out) {
+static int slic_full_impl(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                          const obia_slic_params *params, const ExternalSeeds *ext, int32_t *labels_out, int *n_labels_out) {
     OBIA_TRY(check_ctx(ctx));
     OBIA_TRY(check_slic_args(img, H, W, C, params));
     if (!labels_out) { set_error("null output"); return OBIA_E_INVALID; }
@@ -103,7 +122,7 @@ int obia_slic_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, cons
     int rc;
     {
         ScopedSpan total(ctx, T_TOTAL);
-        rc = slic_single(ctx, img, H, W, C, mask, params, b);
+        rc = slic_single(ctx, img, H, W, C, mask, params, b, ext);
         if (rc == OBIA_OK) {
             if (params->enforce_connectivity) {
                 // segment_size = mask.sum() / n_centroids  |  prod(shape) / n_centroids  (slic_superpixels.py:321-326)
@@ -124,6 +143,27 @@ int obia_slic_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, cons
     resolve_timing(ctx);
     if (n_labels_out) *n_labels_out = n_labels;
     return OBIA_OK;
+}
+
+int obia_slic_assign_only_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                                  const obia_slic_params *params, int32_t *labels_pre_out, int *n_centroids_out) {
+    return slic_assign_only_impl(ctx, img, H, W, C, mask, params, nullptr, labels_pre_out, n_centroids_out);
+}
+
+int obia_slic_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                      const obia_slic_params *params, int32_t *labels_out, int *n_labels_out) {
+    return slic_full_impl(ctx, img, H, W, C, mask, params, nullptr, labels_out, n_labels_out);
+}
+
+int obia_slic_seeded_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,
+                             const obia_slic_params *params, const obia_slic_seeds *seeds, int stage,
+                             int32_t *labels_out, int *n_out) {
+    if (H <= 0 || W <= 0) { set_error("bad image shape"); return OBIA_E_INVALID; }
+    ExternalSeeds ext{};
+    OBIA_TRY(check_seeds(seeds, H, W, ext));
+    if (stage == 1) return slic_assign_only_impl(ctx, img, H, W, C, mask, params, &ext, labels_out, n_out);
+    if (stage != 0) { set_error("stage must be 0 (full) or 1 (labels before connectivity)"); return OBIA_E_INVALID; }
+    return slic_full_impl(ctx, img, H, W, C, mask, params, &ext, labels_out, n_out);
 }
 
 int obia_slic_f32(obia_ctx *ctx, const float *img, int H, int W, int C, const uint8_t *mask,

@@ -504,8 +504,10 @@ int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
     return OBIA_OK;
 }
 
-int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments, const std::vector<int> *nvalid_in) {
+int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments, const std::vector<int> *nvalid_in,
+                       const ExternalSeeds *ext) {
     const int np = b.nprob;
+    if (ext && (np != 1 || ext->n < 1 || !ext->yx)) { set_error("external seeds need one raster and at least one seed"); return OBIA_E_INVALID; }
     Arena &A = ctx->arena;
     // problems carry H, W, pix_off already (set by the caller); upload a first version for the
     // counting / seeding kernels
@@ -522,6 +524,13 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         P.n_valid = nvalid[p];
         SeedGrid &g = grids[p];
         g.cent_off = cent_off; g.pad = 0;
+        if (ext && nvalid[p] > 0) {   // seeds given by the caller: K = their number, step = max(steps) of the seeding
+            g.start_y = g.start_x = 0; g.step_y = g.step_x = 1; g.ny = 1; g.nx = ext->n;
+            stepmax[p] = ext->step < 1.0 ? 1.0 : ext->step;
+            P.cent_off = cent_off;
+            cent_off += ext->n;
+            continue;
+        }
         if (nvalid[p] <= 0 || n_segments[p] <= 0) {   // empty problem: no centroids, every pixel stays masked
             g.start_y = g.start_x = 0; g.step_y = g.step_x = 1; g.ny = g.nx = 0;
             stepmax[p] = 1.0;
@@ -554,7 +563,14 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     OBIA_HIP_TRY(hipMemsetAsync(b.d_cent_prob, 0xff, sizeof(int) * b.total_cent, ctx->stream));
     OBIA_HIP_TRY(hipMemcpyAsync(d_grids, grids.data(), sizeof(SeedGrid) * np, hipMemcpyHostToDevice, ctx->stream));
     std::vector<int> K(np);
-    if (b.masked) {
+    if (ext) {
+        std::vector<float> hs((size_t)ext->n * 2);
+        for (size_t i = 0; i < hs.size(); ++i) hs[i] = (float)ext->yx[i];   // segments.astype(float32): centroids are float
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_cent_prob, 0, sizeof(int) * b.total_cent, ctx->stream));
+        OBIA_HIP_TRY(hipMemcpyAsync(b.d_seed, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, ctx->stream));
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        K[0] = nvalid[0] > 0 ? ext->n : 0;
+    } else if (b.masked) {
         int *d_K = A.get<int>(np);
         if (!d_K) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));

@@ -81,8 +81,11 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
 // Seeds (grid or masked grid), fills K / steps / bins in b.probs, uploads descriptors.
 // n_segments[p] = requested segments of problem p.
 // nvalid (nullable): valid-pixel counts already known to the caller.
+// ext (nullable, single-problem batches only): externally supplied initial centroids -- scikit-image's own
+// _get_mask_centroids output (slic_superpixels.py:14-68) -- instead of the grid rule; step = max(steps).
+struct ExternalSeeds { const double *yx; int n; double step; };
 int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_segments,
-                       const std::vector<int> *nvalid = nullptr);
+                       const std::vector<int> *nvalid = nullptr, const ExternalSeeds *ext = nullptr);
 // valid (unmasked) pixels per problem: mask.sum() (tiling.py:133, slic_superpixels.py:322)
 int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid);
 

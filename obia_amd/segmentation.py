@@ -60,7 +60,7 @@ def _check_common(sigma, spacing, channel_axis, multichannel):
 def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spacing=None, convert2lab=None,
          enforce_connectivity=True, min_size_factor=0.5, max_size_factor=3, slic_zero=False, start_label=1,
          mask=None, *, channel_axis=-1, max_iter=None, multichannel=None, exit_on_fixed_point=False, ctx=None,
-         _normalize_bands=False, _stage="full"):
+         seeds=None, _normalize_bands=False, _stage="full"):
     """Drop-in for ``skimage.segmentation.slic`` on 2-D multichannel rasters (the call at
     obia/segmentation/segment_boundaries.py:51), executed on the GPU.
 
@@ -69,6 +69,9 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
         Computation is float32, obia's raster dtype (obia/handlers/geotif.py:100).
     mask : (H,W) bool/uint8, optional.  Keeps the reference's maskSLIC structure (spatial-only pre-pass)
         with the deterministic masked-grid seeding of DESIGN.md.
+    seeds : ``(centroids_yx (K,2), steps)`` -- initial centroids to use instead of the library's seeding rule, e.g.
+        the output of scikit-image's own ``_get_mask_centroids`` / ``_get_grid_centroids`` (``steps`` as returned
+        there: 3 values, depth axis first, or 2 values (y, x)).  CUDA tensor images only.  Not a scikit-image argument.
     exit_on_fixed_point : stop sweeping once a sweep starts from centroids bit-identical to the previous sweep's
         (every later sweep would reproduce the same labels): same result as all ``max_num_iter`` sweeps, less
         work on rasters that converge early (e.g. compactness 10 on [0,1] features).  Not a scikit-image argument.
@@ -99,6 +102,22 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
         c = ctx or _lib.default_context(dev)
         torch.cuda.current_stream(dev).synchronize()
         out = torch.empty((H, W), dtype=torch.int32, device=img.device)
+        if seeds is not None:
+            yx = np.ascontiguousarray(seeds[0], np.float64)
+            if yx.ndim != 2 or yx.shape[1] != 2:
+                raise ValueError("seeds[0] must be (K, 2) centroid positions (y, x)")
+            st = [float(v) for v in np.ravel(seeds[1])]
+            if len(st) == 2:
+                st = [1.0] + st
+            if len(st) != 3:
+                raise ValueError("seeds[1] must hold 2 (y, x) or 3 (z, y, x) steps")
+            sd = _lib.SlicSeeds()
+            sd.yx, sd.n = yx.ctypes.data, yx.shape[0]
+            sd.steps_zyx[:] = st
+            _lib.check(lib.obia_slic_seeded_f32_dev(c.handle, img.data_ptr(), H, W, C, m.data_ptr() if m is not None else None,
+                                                    ctypes.byref(params), ctypes.byref(sd), {"full": 0, "pre": 1}[_stage],
+                                                    out.data_ptr(), ctypes.byref(n_out)))
+            return out
         fn = {"full": lib.obia_slic_f32_dev, "pre": lib.obia_slic_assign_only_f32_dev}[_stage]
         _lib.check(fn(c.handle, img.data_ptr(), H, W, C, m.data_ptr() if m is not None else None,
                       ctypes.byref(params), out.data_ptr(), ctypes.byref(n_out)))
@@ -118,8 +137,8 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
         m = np.ascontiguousarray(m != 0, dtype=np.uint8)
     c = ctx or _lib.default_context(0)
     out = np.empty((H, W), np.int32)
-    if _stage != "full":
-        raise ValueError("stage-level calls need device tensors")
+    if _stage != "full" or seeds is not None:
+        raise ValueError("stage-level and seeded calls need device tensors")
     _lib.check(lib.obia_slic_f32(c.handle, _lib.np_ptr(img), H, W, C, _lib.np_ptr(m), ctypes.byref(params),
                                  _lib.np_ptr(out), ctypes.byref(n_out)))
     return out.astype(np.int64)

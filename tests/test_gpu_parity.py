@@ -168,6 +168,55 @@ def test_masked_slic_vs_oracle_same_rule(amd, oracle, name):
     assert abs(n_lab - n_gold) <= 0.25 * n_gold
 
 
+@pytest.mark.parametrize("name", [c for c in SLIC_CASES if c.startswith("mask")])
+def test_masked_slic_on_skimage_seeds_vs_golden(amd, name):
+    """maskSLIC pinned on scikit-image itself: the HIP path is fed scikit-image's OWN seeds (the `seeds_yx` /
+    `seed_steps_all` the golden generator took from `_get_mask_centroids`, tests/golden/gen_goldens.py) through the
+    seeds input of the C ABI (obia_slic_seeded_f32_dev) and compared with scikit-image's OUTPUT, not with the oracle:
+    spatial-only pre-pass + main pass (slic_superpixels.py:310-318) -> labels before connectivity <= 1e-4 of pixels,
+    final labels exact or ARI >= 0.99 with the same segment count.  This is the path every tile of
+    create_tiled_segments takes (tiling.py:121-143)."""
+    from obia_amd.segmentation import slic
+    z, params = load(name)
+    raw = dev(z["raw"].astype(np.float32))
+    mask = z["mask"]
+    seeds = (z["seeds_yx"], z["seed_steps_all"])
+    kw = kwargs_of(params)
+    pre = slic(raw, mask=mask, seeds=seeds, _normalize_bands=True, _stage="pre", **kw).cpu().numpy()
+    dis = label_disagreement(pre, z["labels_pre"])
+    assert dis <= 1e-4, f"{name}: {dis:.2e} of pixels differ before connectivity (scikit-image seeds)"
+    lab = slic(raw, mask=mask, seeds=seeds, _normalize_bands=True, **kw).cpu().numpy()
+    gold = z["labels"]
+    assert (lab[mask == 0] == 0).all() and (lab[mask != 0] > 0).all()
+    if not np.array_equal(lab, gold):
+        ari = adjusted_rand_index(lab[mask != 0], gold[mask != 0])
+        assert ari >= 0.99, f"{name}: ARI vs scikit-image {ari}"
+        assert len(np.unique(lab)) == len(np.unique(gold))
+
+
+def test_seeded_slic_rejects_bad_seeds(amd):
+    from obia_amd.segmentation import slic
+    img = dev(np.random.RandomState(0).rand(32, 40, 4).astype(np.float32))
+    with pytest.raises(ValueError):
+        slic(img, seeds=(np.array([[5.0, 50.0]]), [1.0, 8.0, 8.0]), _normalize_bands=True)    # x outside the raster
+    with pytest.raises(ValueError):
+        slic(img, seeds=(np.zeros((0, 2)), [1.0, 8.0, 8.0]), _normalize_bands=True)
+    with pytest.raises(ValueError):
+        slic(img.cpu().numpy(), seeds=(np.array([[5.0, 5.0]]), [1.0, 8.0, 8.0]), _normalize_bands=True)   # host arrays: no seeds
+
+
+def test_seeded_grid_equals_library_seeding(amd, oracle):
+    """Feeding the plain grid through the seeds input must reproduce the library's own grid seeding bit for bit."""
+    from obia_amd.segmentation import slic
+    z, params = load("c2s_256x256x4_c10")
+    raw = dev(z["raw"].astype(np.float32))
+    H, W = z["raw"].shape[:2]
+    yx, steps = oracle.grid_centroids(H, W, params["n_segments"])
+    a = slic(raw, _normalize_bands=True, **kwargs_of(params))
+    b = slic(raw, seeds=(yx.astype(np.float64), steps), _normalize_bands=True, **kwargs_of(params))
+    assert torch.equal(a, b)
+
+
 def test_connectivity_stage_bit_exact_vs_oracle(amd, oracle):
     from obia_amd.segmentation import enforce_connectivity
     z = np.load(os.path.join(GOLD, "connectivity_blackbox.npz"))
