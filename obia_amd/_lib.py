@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libobia_hip.so")
+# OBIA_HIP_LIB: developer override used by kernel experiments (tools/build_variant.sh); still a HIP build of this library
+LIB_PATH = os.environ.get("OBIA_HIP_LIB") or os.path.join(_CSRC, "libobia_hip.so")
 
 OBIA_OK = 0
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_EMPTY, E_NONFINITE = -1, -2, -3, -4, -5, -6

@@ -326,16 +326,17 @@ int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *non
         if (!(v <= 3.0e38f)) { set_error("non-finite feature values"); return OBIA_E_NONFINITE; }
         if (v > maxabs) maxabs = v;
     }
-    // fixed-point scale for the colour sums: totals |feature| * maxcount * 2^s < 2^62, and every partial that is
-    // converted (at most one 128x64 tile of pixels) stays below 2^50 (to_fixed in slic_sweep.hip needs < 2^51)
-    long long maxcount = 1;
-    for (auto &w : b.windows) { long long n = (long long)w.h * w.w; if (n > maxcount) maxcount = n; }
-    double bound = ((double)maxabs + 1e-30) * (double)maxcount;
-    int s = 62 - (int)std::ceil(std::log2(bound + 1.0));
-    const int s2 = 50 - (int)std::ceil(std::log2(((double)maxabs + 1e-30) * (double)(SWEEP_TW * SWEEP_TH) + 1.0));
-    if (s2 < s) s = s2;
-    if (s > 40) s = 40;
-    if (s < -60) s = -60;
+    // fixed-point scale for the colour sums (to_fixed32 in slic_sweep.hip): a power of two with |feature| * 2^s < 2^29, so
+    // that the scaling is exact, the four pixels of a lane's strip add up in an int32 and the total over a cluster of up to
+    // 2^31 pixels stays below 2^60
+    int s = 0;
+    if (maxabs > 0.0f) {
+        int e = 0;
+        (void)std::frexp((double)maxabs, &e);   // maxabs = m * 2^e, m in [0.5, 1)  =>  maxabs < 2^e
+        s = 29 - e;
+    }
+    if (s > 100) s = 100;
+    if (s < -90) s = -90;
     b.fscale = std::ldexp(1.0, s);
     return OBIA_OK;
 }

@@ -10,18 +10,24 @@
 //              truncations), same float32 operation order for d (compiled with -ffp-contract=off), same tie
 //              rule; the sums are exact integers (coordinates) / 64-bit fixed point (colours).
 //
-// Kernel shape (gfx950): one 256-thread workgroup per 128x64 pixel tile.
-//   1. the workgroup stages into LDS the records of every centroid whose window intersects the tile
-//      (lanes walk the per-bin linked lists built by slic_prep_kernel);
-//   2. each wave walks eight 16x16 footprints; a lane owns a 1x4 vertical strip.  Lanes first score the
-//      staged candidates in parallel (one candidate per lane): window-intersects-footprint and a lower
-//      bound `lb` of the spatial term over the footprint; candidates are then visited in ascending lb and
-//      the walk stops when lb exceeds the largest current best distance in the wave (d >= spatial >= lb,
-//      float add/mul are monotone, so nothing that is skipped could have won or tied);
-//   3. the centroid update is fused: per-lane run sums (double) are transposed through a conflict-free LDS
-//      scratch so that 16 lanes x (CP+3) fields fold the wave's 64 strips sequentially, and only the few
-//      resulting (centroid, field) partials touch the workgroup's LDS accumulators (64-bit integer
-//      atomics); one packed global atomic record per (tile, centroid) at the end.
+// Kernel shape (gfx950): one 256-thread workgroup per 64x64 pixel tile (SWEEP_TW x SWEEP_TH, slic.hpp).
+//   1. the workgroup stages into LDS the header of every centroid whose window intersects the tile (lanes walk
+//      the per-bin linked lists built by slic_prep_kernel) and sorts the slots by centroid index k, so that
+//      "lower slot" == "lower k" and the reference's tie rule becomes a comparison of slot numbers;
+//   2. each wave walks four 16x16 footprints (one 16-row band of the tile); a lane owns a 1x4 vertical strip.
+//      Lanes first score the staged candidates in parallel (one candidate per lane): window-intersects-footprint
+//      and a lower bound `lb` of the spatial term over the footprint; candidates are then visited in ascending lb
+//      and the walk stops when lb exceeds the largest current best distance in the wave (d >= spatial >= lb,
+//      float add/mul are monotone, so nothing that is skipped could have won or tied).  A pixel's state is ONE
+//      64-bit key  float_bits(d) << 32 | slot : distances are non-negative floats, whose bit patterns order like
+//      their values, so `new_key < key` is exactly the lexicographic (d, k) comparison of the reference -- no
+//      separate tie path, no second register for the label;
+//   3. the centroid update is fused: every feature is converted once to 32-bit fixed point (a power-of-two scale:
+//      exact for all but the smallest 1/64 of the value range), per-lane run sums are plain int32, they are
+//      transposed through a conflict-free LDS scratch so that 8 lanes x CP fields fold the wave's 64 strips
+//      sequentially, and only the few resulting (centroid, field) partials touch the workgroup's LDS
+//      accumulators (64-bit integer atomics); one packed global atomic record per (tile, centroid) at the end.
+//      Integer sums do not depend on the order of the atomics: the segmentation is bit-reproducible.
 // A tile that meets more candidates than fit in LDS (tiny S, clustered centroids) takes slow_tile(), which
 // reads the bins directly; correctness never depends on the LDS capacity.
 #include "slic.hpp"
@@ -48,9 +54,13 @@ constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
 constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #ifndef LEAN_WAVES
-#define LEAN_WAVES 7
+#define LEAN_WAVES 8
 #endif
-constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); 96 keeps 5 workgroups per CU
+#ifndef ASSIGN_WAVES
+#define ASSIGN_WAVES 5
+#endif
+constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); must stay <= 128: the slot number
+                                // rides in the low 7 bits of the scoring keys
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
 // write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
@@ -96,14 +106,15 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
         const unsigned long long aq = live ? a[q] : 0ull;
         const float oldc = (live && q < CP) ? rec[CENT_REC + q] : 0.0f;
         if (live) a[q] = 0ull;
-        // every lane takes part in the shuffles (dead groups carry zeros)
-        const unsigned long long ny = __shfl(aq, gl0 + CP);
-        const unsigned long long sxq = __shfl(aq, gl0 + CP + 1);
-        const unsigned n = (unsigned)(ny & 0xffffffffull);
-        const float fn = (float)n;
+        // every lane takes part in the shuffles (dead groups carry zeros).  n, sum_y and sum_x are full 64-bit words:
+        // sum_y reaches 2^32 as soon as (pixels of a cluster) x (row) does -- a coarse segmentation of a big raster
+        const unsigned long long nq = __shfl(aq, gl0 + CP);
+        const unsigned long long syq = __shfl(aq, gl0 + CP + 1);
+        const unsigned long long sxq = __shfl(aq, gl0 + CP + 2);
+        const float fn = (float)nq;
         // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
-        cy = (float)(unsigned)(ny >> 32) / fn;
-        cx = (float)(unsigned)sxq / fn;
+        cy = (float)syq / fn;
+        cx = (float)sxq / fn;
         bool mq = false;
         if (live && q < CP) {
             const float sum = (float)((double)(long long)aq * inv_fscale);
@@ -147,14 +158,10 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
 }
 
-// double -> 64-bit fixed point, round to nearest even.  |v * fscale| < 2^51 (the scale is chosen for that in
-// slic_prepare_features), so adding 1.5 * 2^52 leaves the integer in the low mantissa bits: one FMA and one
-// 64-bit subtract instead of the ~10-instruction conversion sequence.
-__device__ __forceinline__ unsigned long long to_fixed(double v, double fscale) {
-    const double magic = 6755399441055744.0;   // 2^52 + 2^51
-    const double t = __fma_rn(v, fscale, magic);
-    return (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(magic));
-}
+// float feature -> 32-bit fixed point.  fs is a power of two chosen in slic_features_finish so that |f * fs| < 2^29:
+// the product is exact, the conversion truncates only what lies below 2^-29 of the largest feature (floats above
+// 1/64 of it are integers after the scaling), four of them add up in an int32 and every total stays below 2^62.
+__device__ __forceinline__ int to_fixed32(float f, float fs) { return (int)(f * fs); }
 
 // ---- wave-wide reductions on DPP (no LDS traffic) ---------------------------------------------------
 // non-negative floats order like their bit patterns, so min/max run on unsigned integers.  Written as
@@ -168,14 +175,8 @@ __device__ __forceinline__ unsigned long long to_fixed(double v, double fscale) 
                  "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"           \
                  "s_nop 1"                                                                        \
                  : "+v"(v))
-__device__ __forceinline__ unsigned wave_umax(unsigned v) {
-    OBIA_WAVE_REDUCE("v_max_u32_dpp");   // every lane now holds the maximum of its row of 16
-    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return max(max(a, b), max(c, d));
-}
 __device__ __forceinline__ unsigned wave_umin(unsigned v) {
-    OBIA_WAVE_REDUCE("v_min_u32_dpp");
+    OBIA_WAVE_REDUCE("v_min_u32_dpp");   // every lane now holds the minimum of its row of 16
     const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
     const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     return min(min(a, b), min(c, d));
@@ -190,15 +191,16 @@ __device__ __forceinline__ void wave_lds_sync() {
     asm volatile("" ::: "memory");
 }
 
+// one pixel straight into the global accumulator record (rare paths only): colours | n | sum_y | sum_x
 template <int CP>
-__device__ __forceinline__ void global_accumulate(unsigned long long *__restrict__ acc, int RQ, int k, unsigned n,
-                                                  unsigned sumy, unsigned long long sumx, const double *sf,
-                                                  double fscale) {
+__device__ __forceinline__ void global_accumulate(unsigned long long *__restrict__ acc, int RQ, int k, unsigned y, unsigned x,
+                                                  const float *f, float fs) {
     unsigned long long *a = acc + (size_t)k * RQ;
 #pragma unroll
-    for (int ch = 0; ch < CP; ++ch) atomicAdd(&a[ch], to_fixed(sf[ch], fscale));
-    atomicAdd(&a[CP], (unsigned long long)n | ((unsigned long long)sumy << 32));
-    atomicAdd(&a[CP + 1], sumx);
+    for (int ch = 0; ch < CP; ++ch) atomicAdd(&a[ch], (unsigned long long)(long long)to_fixed32(f[ch], fs));
+    atomicAdd(&a[CP], 1ull);
+    atomicAdd(&a[CP + 1], (unsigned long long)y);
+    atomicAdd(&a[CP + 2], (unsigned long long)x);
 }
 
 // Fallback for a tile whose candidate set does not fit the LDS slots: every lane scans the bins around
@@ -207,7 +209,8 @@ template <int CP, bool MASKED, bool IGNORE_COLOR, bool SLICZERO>
 __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *__restrict__ feat,
                           const uint8_t *__restrict__ mask, const float *__restrict__ cent,
                           const int *__restrict__ head, const int *__restrict__ next, int32_t *__restrict__ labels,
-                          unsigned long long *__restrict__ acc, int RQ, int accumulate, int start_label, double fscale) {
+                          unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color, int start_label,
+                          float fs) {
     constexpr int RS = CENT_REC + CP;
     const float w = P.spatial_w;
     for (int i = threadIdx.x; i < SWEEP_TW * SWEEP_TH; i += NT) {
@@ -249,10 +252,11 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
             labels[pix] = k - P.cent_off + start_label;
         }
         if (accumulate && k >= 0) {
-            double sf[CP];
+            if (!accum_color) {
 #pragma unroll
-            for (int ch = 0; ch < CP; ++ch) sf[ch] = (double)f[ch];
-            global_accumulate<CP>(acc, RQ, k, 1u, (unsigned)y, (unsigned long long)x, sf, fscale);
+                for (int ch = 0; ch < CP; ++ch) f[ch] = 0.0f;
+            }
+            global_accumulate<CP>(acc, RQ, k, (unsigned)y, (unsigned)x, f, fs);
         }
     }
 }
@@ -281,17 +285,20 @@ __device__ __forceinline__ void slic_assign_body(
     constexpr int RS = CENT_REC + CP;
     constexpr int AQ = LEAN ? 1 : CP + 1;       // qwords of an LDS accumulator: colours (not in the lean kernel), then one packed word
     constexpr int PWI = LEAN ? 0 : CP;          // index of the packed word
-                                                //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 128x64 tile: n <= 8192,
-                                                //   sums <= 8192 * 127 < 2^20: no field can carry into the next)
+                                                //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 64x64 tile: n <= 4096 < 2^16,
+                                                //   sums <= 4096 * 63 < 2^18 in fields of 24 bits: no field can carry into the next)
     constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
+    const float fs = (float)fscale;             // power of two
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
     __shared__ unsigned long long s_acc[MAXC][AQ];
-    __shared__ double s_tf[LEAN ? 1 : NT / 64][LEAN ? 1 : CP][LEAN ? 1 : 65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ int s_tf[LEAN ? 1 : NT / 64][LEAN ? 1 : CP][LEAN ? 1 : 65];    // 65: row stride that keeps the transposed reads conflict-free
     __shared__ int s_tkey[LEAN ? 1 : NT / 64][LEAN ? 1 : 64];
+    __shared__ unsigned s_orph[SWEEP_TH * SWEEP_TW / 32];   // valid pixels no window reached (rare): handled after the footprints
     __shared__ int s_cnt, s_uncacheable;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it lives in scalar registers
     const int ty0 = (tile / P.tiles_x) * SWEEP_TH, tx0 = (tile % P.tiles_x) * SWEEP_TW;
     const int ty1 = min(ty0 + SWEEP_TH, P.H), tx1 = min(tx0 + SWEEP_TW, P.W);
 
@@ -306,17 +313,30 @@ __device__ __forceinline__ void slic_assign_body(
     const bool want_feat = !IGNORE_COLOR || accum_color;
     float f[PPT][LEAN ? 1 : CP];
     bool valid[PPT];
-    auto fetch = [&](int fx0) {
+    // Addresses: one wave-uniform 64-bit base per footprint (scalar registers) plus a 32-bit lane offset -- a pixel's
+    // address costs one or two vector instructions instead of a 64-bit multiply-add chain (16 rows x W x 32 B fits 32
+    // bits: check_slic_args limits W).  The mask bytes and the features of the four pixels are INDEPENDENT loads (all
+    // twelve in flight at once; a masked pixel's features are fetched and never used): a feature load that waits for
+    // its mask byte costs a second full memory round trip per pixel.
+    const unsigned lrow = (unsigned)(PPT * (lane >> 4)) * (unsigned)P.W + (unsigned)(lane & 15);   // pixel 0 of the strip, relative to (fy0, fx0)
+    auto fetch = [&](int fx0, int yb, unsigned lrow) {   // (the lane's row base and offset come in as opaque per-footprint copies)
         const int xx = fx0 + (lane & 15);
+        const long long fbase = P.pix_off + (long long)fy0 * P.W + fx0;      // wave-uniform
+        const uint8_t *mbase = mask + (MASKED ? fbase : 0);
+        const char *fbase_p = reinterpret_cast<const char *>(feat + fbase * (LEAN ? 0 : CP));
+        unsigned char mb[PPT];
+        bool inimg[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const int y = yb + j;
-            bool v = (y < P.H) && (xx < P.W);
-            const long long pix = P.pix_off + (long long)y * P.W + xx;
-            if (MASKED) v = v && (mask[v ? pix : P.pix_off] != 0);
-            valid[j] = v;
-            if (!LEAN && v && want_feat) {
-                const float4 *src = reinterpret_cast<const float4 *>(feat + pix * CP);
+            inimg[j] = (yb + j < P.H) && (xx < P.W);
+            const unsigned off = inimg[j] ? lrow + (unsigned)j * (unsigned)P.W : 0u;
+            mb[j] = MASKED ? mbase[off] : (unsigned char)1;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            if (!LEAN && want_feat) {
+                const unsigned off = inimg[j] ? lrow + (unsigned)j * (unsigned)P.W : 0u;
+                const float4 *src = reinterpret_cast<const float4 *>(fbase_p + (size_t)(off * (unsigned)(CP * 4)));
 #pragma unroll
                 for (int q = 0; q < CP / 4; ++q) {
                     const float4 t = src[q];
@@ -327,9 +347,11 @@ __device__ __forceinline__ void slic_assign_body(
                 for (int c = 0; c < (LEAN ? 1 : CP); ++c) f[j][c] = 0.0f;
             }
         }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) valid[j] = inimg[j] && (mb[j] != 0);
     };
-    if (!FIXPT && wave_active) fetch(tx0);
-    constexpr int GQ = CP + 2;   // global record / cache entry: colours, n | sum_y << 32, sum_x
+    if (!FIXPT && wave_active) fetch(tx0, yb, lrow);
+    constexpr int GQ = CP + 3;   // global record / cache entry: colours, n, sum_y, sum_x
     const int tile_id = P.tile_off + tile;
     // bins whose centroids can reach the tile: candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with
     // y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H)) that needs cy in (ty0 - 2sy - 2, ty1 + 2sy + 1): one pixel
@@ -368,17 +390,19 @@ __device__ __forceinline__ void slic_assign_body(
         atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
     }
     for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
+    for (int i = tid; i < SWEEP_TH * SWEEP_TW / 32; i += NT) s_orph[i] = 0u;
     if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
     __syncthreads();
 
-    if (FIXPT && wave_active) fetch(tx0);
+    if (FIXPT && wave_active) fetch(tx0, yb, lrow);
 
+    auto do_stage = [&]() {
     // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
     {
         for (int bi = tid; bi < nbins; bi += NT) {
             int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
             while (cur >= 0) {
-                // one round trip per list node: the whole record and the link are requested together
+                // one round trip per list node: the whole header and the link are requested together
                 const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
                 const float4 r0 = src[0], r1 = src[1];   // header only: the colours are read at visit time (scalar loads)
                 const int nxt = next[cur];
@@ -396,37 +420,82 @@ __device__ __forceinline__ void slic_assign_body(
         }
     }
     __syncthreads();
-    STAMP(0)   // staging
+    };
+    do_stage();
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
         slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
-                                            start_label, fscale);
+                                                      accum_color, start_label, fs);
         return;
     }
+    auto do_sort = [&]() {
+    // sort the slots by centroid index: slot order == k order, so the reference's tie rule (lowest k wins) is a
+    // comparison of slot numbers and rides in the low word of the pixel keys.  rank = number of smaller k (all distinct).
+    // Waves 0 and 1 hold the k of all slots in two registers (slot = lane, lane + 64) and thread t ranks slot t against
+    // them: a readlane, a compare and an add per slot, no dependent LDS reads.
+    {
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        int rank = -1;
+        if (64 * wv < nc) {   // wave-uniform: the waves that own slots (MAXC <= 128: waves 0 and 1)
+            const int k0 = (lane < nc) ? __float_as_int(s_hdr[lane][6]) : 0x7fffffff;
+            const int k1 = (lane + 64 < nc) ? __float_as_int(s_hdr[lane + 64][6]) : 0x7fffffff;
+            if (tid < nc) {
+                r0 = *reinterpret_cast<const float4 *>(&s_hdr[tid][0]);
+                r1 = *reinterpret_cast<const float4 *>(&s_hdr[tid][4]);
+            }
+            const int myk = (wv == 0) ? k0 : k1;
+            int r = 0;
+            const int n0 = nc < 64 ? nc : 64;
+            for (int i = 0; i < n0; ++i) r += (__builtin_amdgcn_readlane(k0, i) < myk) ? 1 : 0;
+            for (int i = 64; i < nc; ++i) r += (__builtin_amdgcn_readlane(k1, i - 64) < myk) ? 1 : 0;
+            if (tid < nc) rank = r;
+        }
+        __syncthreads();
+        if (rank >= 0) {
+            *reinterpret_cast<float4 *>(&s_hdr[rank][0]) = r0;
+            *reinterpret_cast<float4 *>(&s_hdr[rank][4]) = r1;
+        }
+        __syncthreads();
+    }
+    };
+    do_sort();
+    STAMP(0)   // staging
 
-    // ---- 2. per wave: eight 16x16 footprints (one 16-row band of the 128x64 tile) ----------------------------------------------------------------------
+    constexpr unsigned INF_BITS = 0x7f800000u;
+    // ---- 2. per wave: four 16x16 footprints (one 16-row band of the 64x64 tile) ---------------------------------------
     for (int bxi = 0; wave_active && bxi < SWEEP_TW / FB; ++bxi) {
         const int fx0 = tx0 + FB * bxi;
         if (fx0 >= P.W) break;   // wave-uniform
+        // values derived from the lane's rows are the same in all four footprints; hoisted out of this loop they would sit in
+        // ~25 registers for the whole kernel (and spill): opaque copies keep them one or two instructions away instead
+        int yb_i = yb, lane_i = lane;
+        unsigned lrow_i = lrow;
+        asm volatile("" : "+v"(yb_i), "+v"(lrow_i), "+v"(lane_i));
         const int fx1 = min(fx0 + FB, P.W);
-        const int x = fx0 + (lane & 15);
+        const int x = fx0 + (lane_i & 15);
         const float fx = (float)x;
-        if (bxi > 0) fetch(fx0);
-        // best_d of an invalid pixel is -inf: nothing is ever smaller, so the visits need no `valid` test
-        float best_d[PPT], fyv[PPT];
-        int best_s[PPT], best_k[PPT];   // LDS slot and global index of the best candidate so far
+        if (bxi > 0) fetch(fx0, yb_i, lrow_i);
+        // pixel state: key = float_bits(best distance) << 32 | slot of the best candidate.  Every pixel starts at
+        // (+inf, 0): nothing with d = inf is ever smaller (the reference's `inf > inf` never assigns), and "assigned"
+        // is d < inf.  Masked / outside pixels are evaluated like the others (their features are zeros or unused values)
+        // and discarded at the label stage: the visits never wait for the mask bytes.
+        unsigned long long bk[PPT];
+        float fyv[PPT];
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) { best_d[j] = valid[j] ? INFINITY : -INFINITY; best_s[j] = -1; best_k[j] = -1; fyv[j] = (float)(yb + j); }
+        for (int j = 0; j < PPT; ++j) { bk[j] = (unsigned long long)INF_BITS << 32; fyv[j] = (float)(yb_i + j); }
+#define BK_D(j) __uint_as_float((unsigned)(bk[j] >> 32))
 
         // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
         // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
-        // operation is monotone, so lb <= spatial(pixel) <= d(pixel) for every pixel of the footprint.
-        unsigned lbv[2];
+        // operation is monotone, so lb <= spatial(pixel) <= d(pixel) for every pixel of the footprint.  The scoring key
+        // is lb with its low 7 mantissa bits replaced by the slot number: still a lower bound (rounded DOWN), unique in
+        // the wave, and the wave minimum names its slot without a ballot.
+        unsigned key[2];
         int kkv[2];   // global centroid index of the lane's candidate
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int c = 64 * r + lane;
-            unsigned key = 0xffffffffu;
+            const int c = 64 * r + lane_i;
+            key[r] = 0xffffffffu;
             kkv[r] = 0;
             if (c < nc) {
                 const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
@@ -440,33 +509,24 @@ __device__ __forceinline__ void slic_assign_body(
                     const float rx = (cx < (float)fx0) ? (float)fx0 : ((cx > (float)(fx1 - 1)) ? (float)(fx1 - 1) : cx);
                     const float tyv = cy - ry, txv = cx - rx;
                     const float lb = (tyv * tyv + txv * txv) * w;
-                    key = __float_as_uint(lb);      // lb >= 0: bit pattern order == value order; never 0xffffffff
+                    key[r] = (__float_as_uint(lb) & ~127u) | (unsigned)c;      // lb >= 0 and finite: never 0xffffffff
                 }
             }
-            lbv[r] = key;
         }
 
         STAMP(2)   // scoring
         STAMP_COUNT(0, 1)   // footprints
         // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
-        // a lane's largest current best distance (+inf while one of its valid pixels is unassigned, -inf when it has no
+        // a lane's largest current best distance (+inf while one of its valid pixels is unassigned, 0 when it has no
         // valid pixel): the walk stops when lb exceeds it in every lane -- one compare and a ballot, no wave reduction
-        float mybest = fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3]));
+        float mybest = fmaxf(fmaxf(BK_D(0), BK_D(1)), fmaxf(BK_D(2), BK_D(3)));
         for (;;) {
-            const unsigned mn = wave_umin(min(lbv[0], lbv[1]));
-            if (mn == 0xffffffffu || !__ballot(__uint_as_float(mn) <= mybest)) break;   // equality must still be visited: it can tie on k
-            int c;
-            {
-                const unsigned long long b0 = __ballot(lbv[0] == mn);
-                if (b0) { c = __ffsll((long long)b0) - 1; if (lane == c) lbv[0] = 0xffffffffu; }
-                else {
-                    const unsigned long long b1 = __ballot(lbv[1] == mn);
-                    c = __ffsll((long long)b1) - 1;
-                    if (lane == c) lbv[1] = 0xffffffffu;
-                    c += 64;
-                }
-            }
-            // the candidate's header is wave-uniform: keep it in scalar registers
+            const unsigned mn = wave_umin(min(key[0], key[1]));
+            if (mn == 0xffffffffu) break;
+            if (!__ballot(__uint_as_float(mn & ~127u) <= mybest)) break;   // equality must still be visited: it can tie on k
+            const int c = (int)(mn & 127u);
+            key[0] = (key[0] == mn) ? 0xffffffffu : key[0];
+            key[1] = (key[1] == mn) ? 0xffffffffu : key[1];
             // the candidate's record is read from global memory at a wave-uniform address (its index is lifted out of the
             // scoring lane with one readlane): the scalar unit loads header and colours into SGPRs, no VALU / LDS work
             const int kk = (c & 64) ? __builtin_amdgcn_readlane(kkv[1], c & 63) : __builtin_amdgcn_readlane(kkv[0], c & 63);
@@ -475,127 +535,124 @@ __device__ __forceinline__ void slic_assign_body(
             const float cy = h0.x, cx = h0.y;
             const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
             const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
-            // a window that covers the whole footprint (the common case: windows are ~4S wide) needs no per-pixel test
-            const bool covers = (y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1);
             const float tx = cx - fx;
             const float dx2 = tx * tx;
-            const bool inx = covers || ((x >= x0) && (x < x1));
             float dv[PPT];
-            bool cand[PPT];     // this candidate may still win or tie this pixel
-            bool any = false, improved = false;
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
                 const float tyv = cy - fyv[j];
                 const float dy2 = tyv * tyv;
                 dv[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
-                // colour >= 0 and float add is monotone, so d >= spatial: a candidate whose spatial part already
-                // exceeds the best distance cannot win (equality could still tie on k)
-                bool cnd = !(dv[j] > best_d[j]);
-                if (!covers) cnd = cnd && inx && ((unsigned)(yb + j - y0) < (unsigned)(y1 - y0));
-                cand[j] = cnd;
-                any |= cnd;
             }
+            // a window that covers the whole footprint (the common case: windows are ~4S wide) needs no per-pixel test;
+            // otherwise a pixel outside the window gets the spatial term +inf: `inf < best` never holds, it cannot win
+            if (!((y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1))) {   // wave-uniform
+                const bool inx = (x >= x0) && (x < x1);
+#pragma unroll
+                for (int j = 0; j < PPT; ++j)
+                    dv[j] = (inx && ((unsigned)(yb_i + j - y0) < (unsigned)(y1 - y0))) ? dv[j] : INFINITY;
+            }
+            // colour >= 0 and float add is monotone, so d >= spatial: a candidate whose spatial part already exceeds the best
+            // distance of a pixel cannot win it (equality could still tie on k).  Only the wave-level ballots of that test
+            // are kept: they decide which j-slices evaluate colours at all; the key comparison below needs no mask
+            // (spatial > best  =>  d > best  =>  new key > key).
+            unsigned long long live[PPT];
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) live[j] = __ballot(!(dv[j] > BK_D(j)));
             STAMP_COUNT(1, 1)   // visits
-            STAMP_COUNT(4, __popcll(__ballot(cand[0])) + __popcll(__ballot(cand[1])) + __popcll(__ballot(cand[2])) + __popcll(__ballot(cand[3])))
-            if (any) {
-                STAMP_COUNT(2, 1)   // visits that evaluate colours
-                if (!IGNORE_COLOR) {
-                    float col[CP];
+            STAMP_COUNT(4, __popcll(live[0]) + __popcll(live[1]) + __popcll(live[2]) + __popcll(live[3]))
+            if (!(live[0] | live[1] | live[2] | live[3])) continue;
+            STAMP_COUNT(2, 1)   // visits that evaluate colours
+            float col[LEAN ? 1 : CP];
+            if (!IGNORE_COLOR) {
 #pragma unroll
-                    for (int q = 0; q < CP / 4; ++q) {
-                        const float4 t = crec[2 + q];   // wave-uniform address: scalar loads, the colours stay in SGPRs
-                        col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
-                    }
-#pragma unroll
-                    for (int j = 0; j < PPT; ++j) {
-                        float dc = 0.0f;
-#pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) {
-                            const float t = f[j][LEAN ? 0 : ch] - col[ch];
-                            dc += t * t;
-                        }
-                        // SLIC-zero: the colour term is scaled by the largest colour distance seen in this cluster so far
-                        // (_slic.pyx: dist_center += dist_color / max_dist_color[k])
-                        dv[j] += SLICZERO ? dc / h1.w : dc;
-                    }
-                }
-                // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k).  Exact ties are
-                // rare: the strict comparison is the fast path, ties are resolved on k only when one occurred.
-                bool tie = false;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    const bool lt = cand[j] && (dv[j] < best_d[j]);
-                    tie |= cand[j] && (dv[j] == best_d[j]);
-                    improved |= lt;
-                    best_d[j] = lt ? dv[j] : best_d[j];
-                    best_s[j] = lt ? c : best_s[j];
-                    best_k[j] = lt ? kk : best_k[j];
-                }
-                if (tie) {
-#pragma unroll
-                    for (int j = 0; j < PPT; ++j) {
-                        if (cand[j] && dv[j] == best_d[j] && best_s[j] != c && dv[j] < INFINITY) {   // `inf > inf` never assigns
-                            if (best_s[j] < 0 || kk < best_k[j]) { best_s[j] = c; best_k[j] = kk; }
-                        }
-                    }
+                for (int q = 0; q < CP / 4; ++q) {
+                    const float4 t = crec[2 + q];   // wave-uniform address: scalar loads, the colours stay in SGPRs
+                    col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
                 }
             }
-            if (improved) mybest = fmaxf(fmaxf(best_d[0], best_d[1]), fmaxf(best_d[2], best_d[3]));
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                // the strip is vertical: a candidate above or below the footprint only reaches a few rows, so whole
+                // j-slices of the wave have no live lane and skip the colour arithmetic (wave-uniform branch)
+                if (!live[j]) continue;
+                STAMP_COUNT(3, 1)
+                float d = dv[j];
+                if (!IGNORE_COLOR) {
+                    float dc = 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < CP; ++ch) {
+                        const float t = f[j][LEAN ? 0 : ch] - col[LEAN ? 0 : ch];
+                        dc += t * t;
+                    }
+                    // SLIC-zero: the colour term is scaled by the largest colour distance seen in this cluster so far
+                    // (_slic.pyx: dist_center += dist_color / max_dist_color[k])
+                    d += SLICZERO ? dc / h1.w : dc;
+                }
+                // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k)  ==  min of the keys
+                const unsigned long long nk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)c;
+                bk[j] = (nk < bk[j]) ? nk : bk[j];
+            }
+            mybest = fmaxf(fmaxf(BK_D(0), BK_D(1)), fmaxf(BK_D(2), BK_D(3)));
         }
         STAMP(3)   // visits
 
         // ---- labels ---------------------------------------------------------------------------------------------------
         int pk[PPT];   // accumulation key: LDS slot, or -1
+        int32_t *lbase = labels + (P.pix_off + (long long)fy0 * P.W + fx0);   // wave-uniform
+        bool orphan = false;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const int y = yb + j;
-            const bool inimg = (y < P.H) && (x < P.W);
-            const long long pix = P.pix_off + (long long)y * P.W + x;
-            pk[j] = (valid[j] && best_s[j] >= 0) ? best_s[j] : -1;
-            if (!inimg) continue;
-            if (valid[j] && best_s[j] < 0) {
-                // no window reaches this pixel: `nearest` keeps the previous sweep's value (it is only initialised
-                // once, before the loop) and the pixel is accumulated under it
-                const int prev = labels[pix];
-                if (FIXPT) s_uncacheable = 1;   // this tile's result depends on the previous labels: never replay it
-                if (prev >= start_label && accumulate) {
-                    double one[CP];
-#pragma unroll
-                    for (int ch = 0; ch < CP; ++ch) one[ch] = LEAN ? 0.0 : (double)f[j][LEAN ? 0 : ch];
-                    global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, 1u, (unsigned)y,
-                                          (unsigned long long)x, one, fscale);
-                }
-            } else {
-                __builtin_nontemporal_store((best_s[j] >= 0) ? (best_k[j] - P.cent_off + start_label) : (start_label - 1), &labels[pix]);
+            const bool inimg = (yb_i + j < P.H) && (x < P.W);
+            const bool assigned = valid[j] && ((unsigned)(bk[j] >> 32) < INF_BITS);
+            const int slot = (int)(unsigned)bk[j];
+            pk[j] = assigned ? slot : -1;
+            // a valid pixel no window reaches keeps the previous sweep's label (`nearest` is only initialised once,
+            // before the loop): nothing is stored, the pixel is noted in the tile's bitmap and accumulated under its old
+            // label after the footprints (rare: centroids that drifted away from a thin piece of the mask)
+            const bool orph = valid[j] && !assigned;
+            orphan |= orph;
+            if (inimg && !orph) {
+                const int lab = assigned ? (__float_as_int(s_hdr[slot][6]) - P.cent_off + start_label) : (start_label - 1);
+                __builtin_nontemporal_store(lab, lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
             }
+        }
+        if (__ballot(orphan)) {   // wave-uniform, rare
+#pragma unroll
+            for (int j = 0; j < PPT; ++j)
+                if (valid[j] && ((unsigned)(bk[j] >> 32) >= INF_BITS)) {
+                    const int ry = yb_i + j - ty0, rx = x - tx0;
+                    atomicOr(&s_orph[ry * (SWEEP_TW / 32) + (rx >> 5)], 1u << (rx & 31));
+                    s_uncacheable = 1;   // the tile's result depends on the previous labels: never replay it (exit_on_fixed_point)
+                }
         }
         STAMP(4)   // labels
         if (!accumulate) continue;
 
         // ---- 3. fused centroid update ------------------------------------------------------------------------------------
         // Integer part (n, sum_y, sum_x): one packed 64-bit LDS atomic per run, tile-relative coordinates.
-        // Colour part: per-lane runs of equal slot over the strip, summed in double (exact for 4 floats); the FIRST run
+        // Colour part: per-lane runs of equal slot over the strip, summed as 32-bit fixed point; the FIRST run
         // of every lane goes through the transposed fold below, later runs (a strip crossing a segment boundary) go
         // straight to the LDS accumulators.
-        if (!LEAN && accum_color) s_tkey[wv][lane] = -1;
+        if (!LEAN && accum_color) s_tkey[wv][lane_i] = -1;
         {
             const unsigned long long xrel = (unsigned long long)(x - tx0);
             int rkey = -1, nruns = 0;
             unsigned rn = 0, ry = 0;
-            double rf[CP];
+            int rf[LEAN ? 1 : CP];
 #pragma unroll
-            for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+            for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
             auto close_run = [&]() {
                 if (rkey < 0) return;
                 atomicAdd(&s_acc[rkey][PWI], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
                 if (!LEAN && accum_color) {
                     if (nruns == 0) {   // the lane's slot in the transposed scratch
-                        s_tkey[wv][lane] = rkey;
+                        s_tkey[wv][lane_i] = rkey;
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) s_tf[wv][ch][lane] = rf[ch];
+                        for (int ch = 0; ch < CP; ++ch) s_tf[wv][LEAN ? 0 : ch][lane_i] = rf[LEAN ? 0 : ch];
                     } else {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][LEAN ? 0 : ch], to_fixed(rf[ch], fscale));
+                        for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][LEAN ? 0 : ch], (unsigned long long)(long long)rf[LEAN ? 0 : ch]);
                     }
                 }
                 ++nruns;
@@ -606,13 +663,13 @@ __device__ __forceinline__ void slic_assign_body(
                     close_run();
                     rkey = pk[j]; rn = 0; ry = 0;
 #pragma unroll
-                    for (int ch = 0; ch < CP; ++ch) rf[ch] = 0.0;
+                    for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
                 }
                 if (pk[j] >= 0) {
-                    rn += 1; ry += (unsigned)(yb + j - ty0);
+                    rn += 1; ry += (unsigned)(yb_i + j - ty0);
                     if (!LEAN && accum_color) {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) rf[ch] += (double)f[j][LEAN ? 0 : ch];
+                        for (int ch = 0; ch < CP; ++ch) rf[LEAN ? 0 : ch] += to_fixed32(f[j][LEAN ? 0 : ch], fs);
                     }
                 }
             }
@@ -624,35 +681,49 @@ __device__ __forceinline__ void slic_assign_body(
         wave_lds_sync();
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            const int fld = 8 * pass + (lane & 7), g = lane >> 3;
+            const int fld = 8 * pass + (lane_i & 7), g = lane_i >> 3;
             if (fld < CP) {
                 int cur = -1;
-                double sum = 0.0;
+                long long sum = 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int src = 8 * g + i;
-                    const int key = s_tkey[wv][src];
-                    const double v = key >= 0 ? s_tf[wv][fld][src] : 0.0;   // strips without a run left stale data
-                    if (key != cur) {
-                        if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], to_fixed(sum, fscale));
-                        cur = key; sum = 0.0;
+                    const int tk = s_tkey[wv][src];
+                    const int v = tk >= 0 ? s_tf[wv][LEAN ? 0 : fld][src] : 0;   // strips without a run left stale data
+                    if (tk != cur) {
+                        if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], (unsigned long long)sum);
+                        cur = tk; sum = 0;
                     }
-                    sum += v;
+                    sum += (long long)v;
                 }
-                if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], to_fixed(sum, fscale));
+                if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], (unsigned long long)sum);
             }
         }
         wave_lds_sync();   // the scratch is rewritten by the next footprint
         STAMP(6)   // fold
     }
+#undef BK_D
     if (!accumulate) { STAMP_FLUSH return; }
     __syncthreads();
+    if (s_uncacheable) {   // workgroup-uniform, rare: the orphan pixels of the tile go straight to the global records
+        for (int i = tid; i < SWEEP_TH * SWEEP_TW; i += NT) {
+            if (!((s_orph[i >> 5] >> (i & 31)) & 1u)) continue;
+            const int y = ty0 + i / SWEEP_TW, x = tx0 + i % SWEEP_TW;
+            const long long pix = P.pix_off + (long long)y * P.W + x;
+            const int prev = labels[pix];
+            if (prev < start_label) continue;
+            float one[CP];
+#pragma unroll
+            for (int ch = 0; ch < CP; ++ch) one[ch] = accum_color ? feat[pix * CP + ch] : 0.0f;
+            global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, (unsigned)y, (unsigned)x, one, fs);
+        }
+    }
     // ---- LDS accumulators -> global records: consecutive lanes write consecutive qwords of one 128-B record -----------
     // (with exit_on_fixed_point the same values are kept, slot by slot, as the tile's cache for the sweeps that replay them)
     const bool keep = FIXPT && !s_uncacheable;
     int *ck = keep ? cache_k + (size_t)tile_id * (MAXC + 1) : nullptr;
     unsigned long long *cq = keep ? cache_q + (size_t)tile_id * MAXC * GQ : nullptr;
-    // (the lean kernel without the fixed-point cache only has the two integer words of every record to send)
+    // (the lean kernel without the fixed-point cache only has the three integer words of every record to send)
     constexpr int QLO = (LEAN && !FIXPT) ? CP : 0, QN = GQ - QLO;
     for (int i = tid; i < nc * QN; i += NT) {
         const int slot = i / QN, q = QLO + (i - slot * QN);
@@ -663,7 +734,8 @@ __device__ __forceinline__ void slic_assign_body(
         const int k = __float_as_int(s_hdr[slot][6]);
         unsigned long long v;
         if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][LEAN ? 0 : q] : 0ull; }
-        else if (q == CP) v = n | ((((pw >> 16) & 0xffffffull) + n * (unsigned long long)ty0) << 32);
+        else if (q == CP) v = n;
+        else if (q == CP + 1) v = ((pw >> 16) & 0xffffffull) + n * (unsigned long long)ty0;
         else v = (pw >> 40) + n * (unsigned long long)tx0;
         if (FIXPT && keep) cq[(size_t)slot * GQ + q] = v;
         if (FIXPT && q < CP && !accum_color) continue;
@@ -685,13 +757,13 @@ __device__ __forceinline__ void slic_assign_body(
     probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, accum_color, start_label, fscale, bin_stamp, tile_lp, \
         cache_k, cache_q, sweep_id, use_cache, px_counter
 
-// the colour sweeps and the last pre-pass sweep: 96 VGPRs, 27 KB of LDS, five waves per SIMD
+// the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void slic_assign_kernel(OBIA_ASSIGN_PARAMS) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ASSIGN_WAVES, ASSIGN_WAVES))) void slic_assign_kernel(OBIA_ASSIGN_PARAMS) {
     slic_assign_body<CP, MASKED, IGNORE_COLOR, FIXPT, SLICZERO, false>(OBIA_ASSIGN_ARGS);
 }
 
-// the pre-pass sweeps that fold no colours: no feature registers, 10 KB of LDS, eight waves per SIMD
+// the pre-pass sweeps that fold no colours: no feature registers, 4 KB of LDS
 template <int CP, bool MASKED, bool FIXPT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LEAN_WAVES, LEAN_WAVES))) void slic_prepass_kernel(OBIA_ASSIGN_PARAMS) {
     slic_assign_body<CP, MASKED, true, FIXPT, false, true>(OBIA_ASSIGN_ARGS);
@@ -799,7 +871,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         fp.bin_stamp = A.get<int>((size_t)b.total_cells);
         fp.tile_lp = A.get<int>(nt);
         fp.cache_k = A.get<int>(nt * (MAXC + 1));
-        fp.cache_q = A.get<unsigned long long>(nt * MAXC * (size_t)(b.CP + 2));
+        fp.cache_q = A.get<unsigned long long>(nt * MAXC * (size_t)(b.CP + 3));
         if (!fp.bin_stamp || !fp.tile_lp || !fp.cache_k || !fp.cache_q) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(fp.bin_stamp, 0, sizeof(int) * (size_t)b.total_cells, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(fp.tile_lp, 0, sizeof(int) * nt, ctx->stream));
