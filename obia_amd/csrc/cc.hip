@@ -488,7 +488,7 @@ __global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_
 // final labels: survivors get rank + start_label; small components follow their adjacency chain
 __global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__ parent, const int *__restrict__ newlab,
                                                          const int *__restrict__ target, long long n, int start_label,
-                                                         int mask_label, int32_t *__restrict__ out) {
+                                                         int mask_label, int max_hops, int32_t *__restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int r = parent[i];
         int res;
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__
             int hops = 0;
             while (nl < 0) {
                 const int t = target[-nl - 2];
-                if (t < 0 || ++hops > 64) { nl = -1; break; }
+                // a chain only leads to components that settled EARLIER: it is acyclic and at most n_small long
+                if (t < 0 || ++hops > max_hops) { nl = -1; break; }
                 nl = newlab[parent[t]];
             }
             res = (nl >= 0) ? nl + start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
@@ -580,7 +581,10 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         // optimistic start (every small component labelled at its first pixel), then Jacobi rounds until the
         // settle times stop moving; one round settles everything unless small components that find no
         // labelled neighbour touch each other
-        for (int round = 0; round < 32; ++round) {
+        // (settle times only move forward and are bounded, so the rounds end; a chain of k small components that touch
+        // each other needs at most k rounds -- never cut short: an unconverged round would write label 0)
+        bool converged = false;
+        for (int round = 0; round <= n_small + 1; ++round) {
             OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
                                small_list, small_qoff, n_small, start_label, settle_a, settle_b, queue, labels_out, target,
@@ -588,11 +592,12 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
             int changed = 0;
             OBIA_TRY(read_back(ctx, &changed, counters + 5, sizeof(int)));
             std::swap(settle_a, settle_b);
-            if (!changed) break;
+            if (!changed) { converged = true; break; }
         }
+        if (!converged) { set_error("connectivity enforcement: settle rounds did not converge (%d small components)", n_small); return OBIA_E_INVALID; }
     }
     hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
-                       mask_label, labels_out);
+                       mask_label, n_small + 1, labels_out);
     OBIA_HIP_TRY(hipGetLastError());
     if (h_n_labels_out) *h_n_labels_out = n_surv;
     return OBIA_OK;

@@ -858,6 +858,9 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
     }
     if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
+    // the sweep addresses a footprint's pixels as a 64-bit wave-uniform base plus a 32-bit lane offset (16 rows x W x 64 B)
+    for (auto &P : b.probs)
+        if (P.W >= (1 << 22)) { set_error("rasters / tile windows wider than 4194303 pixels are not supported (got %d)", P.W); return OBIA_E_UNSUPPORTED; }
     const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
     const int RQ = acc_record_qwords(b.CP);
     Arena &A = ctx->arena;

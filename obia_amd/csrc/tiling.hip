@@ -531,6 +531,9 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
     // white tile rows of ONE parity class do not see each other (their windows are T - 2B rows apart): the whole class is
     // one batch; in raster order every row sees the corner overlaps of the row before it: one batch per row
     const bool per_row = !(parity >= 0 && T > 2 * B);
+    // tile_size <= 2 * buffer: the grown windows of two white tiles of ONE tile row overlap (they are T - 2B columns apart), so
+    // even a row cannot be one batch -- every white tile runs on its own, in the reference's order (tiling.py:156-287)
+    const bool per_tile = white && T <= 2 * B;
     std::vector<TileWin> wins;
     auto flush = [&]() -> int {
         for (auto &t : wins)
@@ -550,6 +553,7 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
             } else {
                 const TileWin t = white_window(S, tj, ti);
                 if (t.h > 0 && t.w > 0) wins.push_back(t);
+                if (per_tile && !wins.empty()) OBIA_TRY(flush());
             }
         }
         if (white && per_row) OBIA_TRY(flush());

@@ -77,3 +77,51 @@ def test_tiled_8192_properties():
     tot = (st["mean"][:, 0] * st["count"].to(torch.float64)).sum().item()
     ref = img[:, :, 0].to(torch.float64)[lab > 0].sum().item()
     assert abs(tot - ref) <= 1e-9 * abs(ref)
+
+
+def test_config3_full_size_16384_properties():
+    """BASELINE configs[2] at FULL size -- the bench workload itself: 16384 x 16384 x 8, create_tiled_segments(tile 2048,
+    overlap 64, crown radius 5, 0.5 m pixels) + zonal statistics.  No oracle finishes this in seconds; checked through
+    size-independent properties: ids 1..N all present (tiling.py:289-290), holes only where the reference leaves them (the
+    two bottom corner squares of the 32 white windows), the crown-rule density, every labelled pixel counted exactly once by
+    the statistics, a checksum of the per-segment means against a direct sum over the raster, float64 recomputation of
+    sampled segments, and bit-identical labels on a second run."""
+    from obia_amd.tiling import create_tiled_segments
+    from obia_amd.statistics import zonal_stats
+    H = W = 16384
+    img = synth_gpu(H, W, 8)
+    kw = dict(tile_size=2048, buffer=64, crown_radius=5, pixel_size=(0.5, 0.5), compactness=10.0)
+    mask = torch.ones((H, W), dtype=torch.uint8, device="cuda")
+    lab, n = create_tiled_segments(img, input_mask=mask, **kw)
+    lab2, n2 = create_tiled_segments(img, input_mask=mask, **kw)
+    assert n == n2 and torch.equal(lab, lab2)
+    del lab2
+    assert int(lab.max().item()) == n and int(lab.min().item()) >= 0
+    present = torch.bincount(lab.reshape(-1), minlength=n + 1)
+    assert int((present[1:] == 0).sum().item()) == 0               # ids 1..N all used
+    holes = int(present[0].item())
+    assert holes <= 32 * 2 * 64 * 64                                # corner squares: buffer/2 = 32 m = 64 px a side
+    expected = H * W * 0.25 / (np.pi * 25)                          # crown rule: one segment per pi * r^2 of map area
+    assert 0.95 * expected <= n <= 1.1 * expected
+    sizes = present[1:]
+    assert int(sizes.min().item()) >= 1 and int(sizes.max().item()) <= 3 * 2176 * 2176 // 13000
+    st = zonal_stats(img, lab, n_labels=n)
+    assert torch.equal(st["count"], sizes.to(st["count"].dtype))    # every labelled pixel counted once, under its own id
+    band = img[:, :, 3].to(torch.float64)
+    tot = (st["mean"][:, 3] * st["count"].to(torch.float64)).sum().item()
+    ref = band[lab > 0].sum().item()
+    assert abs(tot - ref) <= 1e-9 * abs(ref)
+    assert float(st["min"][:, 3].min().item()) == float(band[lab > 0].min().item())
+    assert float(st["max"][:, 3].max().item()) == float(band[lab > 0].max().item())
+    del band
+    for v in (1, 4242, n // 2, n):                                  # sampled segments, recomputed in float64
+        ys, xs = torch.nonzero(lab == v, as_tuple=True)
+        px = img[ys, xs].to(torch.float64)
+        assert px.shape[0] == int(st["count"][v - 1].item())
+        torch.testing.assert_close(st["mean"][v - 1], px.mean(0), rtol=1e-6, atol=0)
+        torch.testing.assert_close(st["variance"][v - 1], px.var(0, unbiased=False), rtol=1e-5, atol=1e-6)
+        # one 4-connected component per id: flood from the first pixel inside the bounding box
+        y0, y1, x0, x1 = int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1
+        from scipy import ndimage
+        sub = (lab[y0:y1, x0:x1] == v).cpu().numpy()
+        assert ndimage.label(sub, ndimage.generate_binary_structure(2, 1))[1] == 1

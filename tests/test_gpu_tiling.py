@@ -1,7 +1,10 @@
 """GPU parity of the tiled driver (B3, obia_tiled_slic_f32) against the oracle's restatement of
 create_tiled_segments on label rasters (oracle/tiler.py).  The reference's tiler needs GDAL/shapely and has no
 fixtures: this stage is "parity unpinned" (DESIGN.md); what is checked is that the HIP tile loops, seam
-rules, crown rule and id order equal the CPU restatement built on the pinned SLIC oracle."""
+rules, crown rule, size cuts and id order equal the CPU restatement built on the pinned SLIC oracle -- EXACTLY:
+both sides use the same seeding rule and the per-tile SLIC is bit-exact on non-Lab inputs, so the label rasters
+must be identical pixel for pixel (the one 3-band case goes through rgb2lab, device powf/cbrtf vs libm, and keeps the
+stated ARI / boundary tolerance)."""
 import numpy as np
 import pytest
 
@@ -23,6 +26,16 @@ CASES = [
     dict(H=256, W=256, C=8, tile_size=128, buffer=32, crown_radius=5, pixel_size=(0.5, 0.5), compactness=10.0),
     dict(H=230, W=410, C=4, tile_size=100, buffer=20, crown_radius=4, pixel_size=(1.0, 1.0), compactness=0.25),
     dict(H=200, W=200, C=3, tile_size=200, buffer=30, crown_radius=5, pixel_size=(1.0, 1.0), compactness=10.0),  # single tile
+    # 8 bands at the author's compactness (notebooks/deepfor.ipynb:402): the colour term decides the boundaries
+    dict(H=256, W=300, C=8, tile_size=128, buffer=24, crown_radius=4, pixel_size=(1.0, 1.0), compactness=0.25),
+    # ragged segments + a small max_size_factor: the connectivity stage cuts components at max_size inside the tiler
+    # (slic's max_size_factor reaches every tile through **kwargs, tiling.py:137-143)
+    dict(H=300, W=340, C=4, tile_size=100, buffer=16, crown_radius=5, pixel_size=(1.0, 1.0), compactness=0.05, max_size_factor=1.2),
+    dict(H=260, W=260, C=5, tile_size=128, buffer=20, crown_radius=6, pixel_size=(1.0, 1.0), compactness=0.05, max_size_factor=1.05,
+         min_size_factor=0.25),
+    # tile_size <= 2 * buffer: grown windows of neighbouring white tiles of one row overlap; the driver must fall back to the
+    # reference's one-tile-at-a-time order
+    dict(H=150, W=170, C=4, tile_size=40, buffer=24, crown_radius=3, pixel_size=(1.0, 1.0), compactness=1.0),
 ]
 
 
@@ -36,11 +49,17 @@ def test_tiled_vs_oracle(oracle, case):
     ref, n_ref = tiler.create_tiled_segments(img, mask, **c)
     lab, n = create_tiled_segments(img, input_mask=mask, **c)
     assert lab.shape == ref.shape and lab.dtype == np.int32
-    assert ((lab == 0) == (ref == 0)).mean() >= 0.9999
-    ari = adjusted_rand_index(lab, ref)
-    rec, prec = boundary_recall_precision(ref, lab)
-    assert ari >= 0.99 and rec >= 0.99 and prec >= 0.99, f"ARI {ari} recall {rec} precision {prec}"
-    assert abs(n - n_ref) <= max(1, 0.01 * n_ref)
+    if img.shape[2] == 3:      # Lab: stated tolerance
+        assert ((lab == 0) == (ref == 0)).mean() >= 0.9999
+        ari = adjusted_rand_index(lab, ref)
+        rec, prec = boundary_recall_precision(ref, lab)
+        assert ari >= 0.99 and rec >= 0.99 and prec >= 0.99, f"ARI {ari} recall {rec} precision {prec}"
+        assert abs(n - n_ref) <= max(1, 0.01 * n_ref)
+    else:
+        assert n == n_ref and np.array_equal(lab, ref), f"{(lab != ref).sum()} px differ, n {n} vs {n_ref}"
+    if "max_size_factor" in c:   # the cut really fires in these cases: without it the partition is another one
+        _, n_nocut = tiler.create_tiled_segments(img, mask, **dict(c, max_size_factor=1e9))
+        assert n_nocut != n_ref
     ids = np.unique(lab[lab > 0])
     assert ids[0] == 1 and ids[-1] == n and len(ids) == n          # segment_id = 1..N (tiling.py:289-290)
 
@@ -56,8 +75,7 @@ def test_tiled_with_mask_and_empty_tiles(oracle):
     ref, n_ref = tiler.create_tiled_segments(img, mask, **kw)
     lab, n = create_tiled_segments(img, input_mask=mask, **kw)
     assert (lab[~mask] == 0).all()
-    assert adjusted_rand_index(lab, ref) >= 0.99
-    assert abs(n - n_ref) <= max(1, 0.02 * n_ref)
+    assert n == n_ref and np.array_equal(lab, ref), f"{(lab != ref).sum()} px differ, n {n} vs {n_ref}"
     # device-tensor entry gives the identical raster (determinism: integer accumulators, no atomics on floats)
     lab2, n2 = create_tiled_segments(torch.as_tensor(img).cuda(), input_mask=mask, **kw)
     assert n2 == n and np.array_equal(lab2.cpu().numpy(), lab)
