@@ -236,13 +236,37 @@ def normalize_band(band):
     return (band - np.min(band)) / (np.max(band) - np.min(band))
 
 
-def create_segments(image, segmentation_bands=None, method="slic", inplace_normalize=False, ctx=None, **kwargs):
-    """Array-level mirror of obia create_segments (segment_boundaries.py:18-78).
+def segments_table(labels, image=None, start_label=0, ctx=None):
+    """The table the reference's create_segments returns (segment_boundaries.py:59-77): one row per segment with
+    ``geometry`` (polygon in map coordinates through ``image.affine_transformation``; WKB bytes, or shapely geometries in a
+    GeoDataFrame when geopandas is installed) and ``segment_id`` = 1..N in ascending label order; labels below
+    ``start_label`` (the -1 of masked pixels) get no row.  The label raster rides along in ``attrs["labels"]`` so that
+    create_objects can take the table like the reference takes its GeoDataFrame."""
+    import pandas as pd
+    from .polygons import polygonize
+    pt = polygonize(labels, affine_transformation=getattr(image, "affine_transformation", None), start_label=start_label, ctx=ctx)
+    wkb = pt.wkb()
+    crs = getattr(image, "crs", None)
+    try:
+        import geopandas as gpd
+        import shapely
+        df = gpd.GeoDataFrame(geometry=list(shapely.from_wkb(wkb)), crs=crs)
+    except ImportError:
+        df = pd.DataFrame({"geometry": wkb})
+    df["segment_id"] = range(1, len(df) + 1)
+    df.attrs["labels"] = labels
+    df.attrs["crs"] = crs
+    return df
+
+
+def create_segments(image, segmentation_bands=None, method="slic", inplace_normalize=False, as_table=False, ctx=None, **kwargs):
+    """Mirror of obia create_segments (segment_boundaries.py:18-78).
 
     ``image``: object with ``img_data`` (H,W,C) float32 (obia ``Image``), or the array itself.
     Returns the label raster (H,W) int64: labels consecutive from ``start_label`` (default 1), and -1
-    where ``mask == 0`` (segment_boundaries.py:55-57).  Polygonisation into a GeoDataFrame
-    (segment_boundaries.py:59-77) is the next stage outside this path.
+    where ``mask == 0`` (segment_boundaries.py:55-57).  ``as_table=True`` returns what the reference returns instead --
+    the ``geometry`` / ``segment_id`` table of :func:`segments_table` (segment_boundaries.py:59-77), polygons from the
+    GPU polygoniser.
 
     Every band of the raster is min-max normalised before band selection, as the reference does
     (:32-33) -- on the GPU, on a private copy: the caller's ``img_data`` is NOT mutated unless
@@ -270,7 +294,7 @@ def create_segments(image, segmentation_bands=None, method="slic", inplace_norma
         if inplace_normalize and not _is_torch(img_data):
             for i in range(num_bands):
                 img_data[:, :, i] = normalize_band(img_data[:, :, i])
-        return segments
+        return segments_table(segments, image, start_label=0, ctx=ctx) if as_table else segments
     unknown = [k for k in kwargs if k not in _SLIC_KWARGS]
     if unknown:
         raise TypeError(f"slic() got an unexpected keyword argument '{unknown[0]}'")
@@ -286,7 +310,9 @@ def create_segments(image, segmentation_bands=None, method="slic", inplace_norma
             segments[torch.as_tensor(mask, device=segments.device) == 0] = -1
         else:
             segments[np.asarray(mask) == 0] = -1
-    return segments
+    # the reference skips only the id -1 (:62-64); with start_label=1 and no mask every label >= 1, with start_label=0 the
+    # label 0 is a segment like any other
+    return segments_table(segments, image, start_label=0 if mask is None else kwargs["start_label"], ctx=ctx) if as_table else segments
 
 
 class Segments:
@@ -307,10 +333,30 @@ class Segments:
         return polygonize(self._segments, affine_transformation=affine_transformation, start_label=start_label, ctx=ctx)
 
     def write_segments(self, file_path):
+        """segment.py:55-60 (``self.segments.to_file(file_path)``): GeoDataFrame.to_file when geopandas is there; else a
+        GeoPackage written by obia_amd.geopackage (``.gpkg``) or a CSV without the geometry."""
         if hasattr(self.segments, "to_file"):
             self.segments.to_file(file_path)
+        elif str(file_path).lower().endswith(".gpkg") and "geometry" in self.segments and len(self.segments) \
+                and isinstance(self.segments["geometry"].iloc[0], (bytes, bytearray)):
+            from .geopackage import write_geopackage
+            cols = {c: self.segments[c].to_numpy() for c in self.segments.columns if c != "geometry"}
+            write_geopackage(file_path, list(self.segments["geometry"]), cols, table="segments",
+                             srs_epsg=_epsg_of(self.segments.attrs.get("crs")))
         else:
-            self.segments.to_csv(file_path, index=False)
+            self.segments.drop(columns=[c for c in ("geometry",) if c in self.segments]).to_csv(file_path, index=False)
+
+
+def _epsg_of(crs):
+    """EPSG code of ``image.crs`` when it is spelled as one ("EPSG:32610", 32610); None otherwise (no pyproj here)."""
+    if crs is None:
+        return None
+    if isinstance(crs, int):
+        return crs
+    txt = str(crs).strip().upper()
+    if txt.startswith("EPSG:") and txt[5:].isdigit():
+        return int(txt[5:])
+    return int(txt) if txt.isdigit() else None
 
 
 def segment(image, segmentation_bands=None, statistics_bands=None, method="slic", calc_mean=True, calc_variance=True,
@@ -323,9 +369,12 @@ def segment(image, segmentation_bands=None, statistics_bands=None, method="slic"
     """
     from .statistics import create_objects
     labels = create_segments(image, segmentation_bands=segmentation_bands, method=method, ctx=ctx, **kwargs)
+    # ids of the objects table: every label the segmentation produced.  quickshift numbers from 0; slic from start_label
+    # (0 or 1), and with a mask the masked pixels carry -1 (segment_boundaries.py:55-64 skips only that id)
+    first = 0 if method == "quickshift" else int(kwargs.get("start_label", 1))
     objects = create_objects(labels, image, spectral_bands=statistics_bands, calc_mean=calc_mean,
                              calc_variance=calc_variance, calc_skewness=calc_skewness, calc_kurtosis=calc_kurtosis,
                              calc_contrast=calc_contrast, calc_dissimilarity=calc_dissimilarity,
                              calc_homogeneity=calc_homogeneity, calc_ASM=calc_ASM, calc_energy=calc_energy,
-                             calc_correlation=calc_correlation, ctx=ctx)
+                             calc_correlation=calc_correlation, start_label=first, ctx=ctx)
     return Segments(labels, objects, method, **kwargs)

@@ -153,12 +153,18 @@ def texture_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=Non
     return res
 
 
+POINTCLOUD_STATS = ("pai", "fhd", "ch", "mean_intensity", "variance_intensity")
+
+
 def stats_columns(spectral_bands, textural_bands=(), calc_mean=True, calc_variance=True, calc_min=True, calc_max=True,
                   calc_skewness=True, calc_kurtosis=True, calc_contrast=True, calc_dissimilarity=True,
-                  calc_homogeneity=True, calc_ASM=True, calc_energy=True, calc_correlation=True):
+                  calc_homogeneity=True, calc_ASM=True, calc_energy=True, calc_correlation=True,
+                  calc_pai=False, calc_fhd=False, calc_ch=False, calc_mean_intensity=False, calc_variance_intensity=False,
+                  geometry=False):
     """Column names and order of the objects table: segment_id, then per spectral band
-    mean/variance/min/max/skewness/kurtosis, then per textural band the six GLCM properties
-    (obia _create_empty_stats_columns, segment_statistics.py:12-110)."""
+    mean/variance/min/max/skewness/kurtosis, then per textural band the six GLCM properties, then the point-cloud
+    statistics whose flags are set, then ``geometry`` (obia _create_empty_stats_columns, segment_statistics.py:12-110).
+    create_objects passes the reference's defaults (all five point-cloud flags True, geometry last)."""
     cols = ["segment_id"]
     spec = [("mean", calc_mean), ("variance", calc_variance), ("min", calc_min), ("max", calc_max),
             ("skewness", calc_skewness), ("kurtosis", calc_kurtosis)]
@@ -168,20 +174,39 @@ def stats_columns(spectral_bands, textural_bands=(), calc_mean=True, calc_varian
            ("ASM", calc_ASM), ("energy", calc_energy), ("correlation", calc_correlation)]
     for b in textural_bands:
         cols += [f"b{b}_{name}" for name, on in tex if on]
+    cols += [name for name, on in zip(POINTCLOUD_STATS, (calc_pai, calc_fhd, calc_ch, calc_mean_intensity,
+                                                         calc_variance_intensity)) if on]
+    if geometry:
+        cols.append("geometry")
     return cols
 
 
-def create_objects(segments, image, spectral_bands=None, textural_bands=None, calculate_spectral=True,
-                   calculate_textural=False, calculate_structural=False, calculate_radiometric=False, ept=None,
-                   calc_mean=True, calc_variance=True, calc_min=True, calc_max=True, calc_skewness=True,
-                   calc_kurtosis=True, calc_contrast=True, calc_dissimilarity=True, calc_homogeneity=True, calc_ASM=True,
-                   calc_energy=True, calc_correlation=True, start_label=1, ctx=None):
-    """Array-level mirror of obia create_objects (segment_statistics.py:392-511).
+def _labels_of(segments):
+    """The label raster behind ``segments``: the raster itself, or the table create_segments(as_table=True) returned
+    (its ``attrs["labels"]``)."""
+    if hasattr(segments, "attrs") and "labels" in getattr(segments, "attrs", {}):
+        return segments.attrs["labels"], segments
+    return segments, None
 
-    ``segments``: the label raster from create_segments (one 4-connected component per label, so "pixels
-    inside polygon p" are "pixels carrying label p").  ``image``: object with ``img_data`` or
-    the raw (H,W,C) array.  Returns a pandas DataFrame whose columns follow the reference's order;
-    mean/variance/min/max, skewness/kurtosis and the six GLCM texture statistics come from the GPU passes.
+
+def create_objects(segments, image, ept=None, ept_srs=None, spectral_bands=None, textural_bands=None, voxel_resolution=None,
+                   calculate_spectral=True, calculate_textural=True, calculate_structural=False, calculate_radiometric=False,
+                   calc_mean=True, calc_variance=True, calc_min=True, calc_max=True, calc_skewness=True, calc_kurtosis=True,
+                   calc_contrast=True, calc_dissimilarity=True, calc_homogeneity=True, calc_ASM=True, calc_energy=True,
+                   calc_correlation=True, calc_pai=True, calc_fhd=True, calc_ch=True, calc_mean_intensity=True,
+                   calc_variance_intensity=True, *, start_label=1, geometry=True, ctx=None):
+    """Mirror of obia create_objects (segment_statistics.py:392-511): same positional order, same defaults, same column
+    set and order -- ``calculate_textural`` defaults to True, the five point-cloud columns are present and NaN (their flags
+    default to True while the point-cloud workflow itself raises, :435-439), ``geometry`` comes last.
+
+    ``segments``: the label raster from create_segments (one 4-connected component per label, so "pixels inside polygon p"
+    are "pixels carrying label p") or the table create_segments(as_table=True) returned.  ``image``: object
+    with ``img_data`` (and optionally ``affine_transformation`` / ``crs``) or the raw (H,W,C) array.  Labels below
+    ``start_label`` (the -1 / 0 of masked pixels) get no row; ``segment_id`` = 1..N in ascending label order
+    (segment_boundaries.py:76).
+    ``geometry``: True -> one polygon per segment from the GPU polygoniser (WKB bytes; shapely geometries in a
+    GeoDataFrame when geopandas is installed); False -> the column holds None (skips the polygon pass).
+    Spectral statistics are always computed, like the reference's loop (:487-491 does not test ``calculate_spectral``).
     """
     import pandas as pd
     if not (calculate_spectral or calculate_textural or calculate_structural or calculate_radiometric):
@@ -190,34 +215,63 @@ def create_objects(segments, image, spectral_bands=None, textural_bands=None, ca
     if ept is not None or calculate_structural or calculate_radiometric:
         raise NotImplementedError("Point-cloud workflows are temporarily disabled. "
                                   "Use spectral/textural statistics only for now.")
+    labels, seg_table = _labels_of(segments)
     img_data = image.img_data if hasattr(image, "img_data") else image
     C = img_data.shape[2]
     if spectral_bands is None:
         spectral_bands = list(range(C))
-    tex_bands = list(textural_bands) if (calculate_textural and textural_bands is not None) else (
-        list(range(C)) if calculate_textural else [])
-    st = zonal_stats(img_data, segments, bands=spectral_bands, start_label=start_label, ctx=ctx,
+    if textural_bands is None:
+        textural_bands = list(range(C))
+    spectral_bands, textural_bands = list(spectral_bands), list(textural_bands)
+    st = zonal_stats(img_data, labels, bands=spectral_bands, start_label=start_label, ctx=ctx,
                      moments=bool(calc_skewness or calc_kurtosis))
     if _is_torch(st["count"]):
         st = {k: (v.cpu().numpy() if _is_torch(v) else v) for k, v in st.items()}
     n = st["count"].shape[0]
-    cols = stats_columns(spectral_bands, tex_bands, calc_mean, calc_variance, calc_min, calc_max, calc_skewness,
+    present = st["count"] > 0                      # ids of the table: the labels that exist (np.unique order)
+    cols = stats_columns(spectral_bands, textural_bands, calc_mean, calc_variance, calc_min, calc_max, calc_skewness,
                          calc_kurtosis, calc_contrast, calc_dissimilarity, calc_homogeneity, calc_ASM, calc_energy,
-                         calc_correlation)
-    data = {"segment_id": np.arange(1, n + 1)}
+                         calc_correlation, calc_pai, calc_fhd, calc_ch, calc_mean_intensity, calc_variance_intensity,
+                         geometry=True)
+    n_rows = int(present.sum())
+    data = {"segment_id": np.arange(1, n_rows + 1)}
     for j, b in enumerate(spectral_bands):
-        for name, key, on in (("mean", "mean", calc_mean), ("variance", "variance", calc_variance),
-                              ("min", "min", calc_min), ("max", "max", calc_max),
-                              ("skewness", "skewness", calc_skewness), ("kurtosis", "kurtosis", calc_kurtosis)):
+        for name, on in (("mean", calc_mean), ("variance", calc_variance), ("min", calc_min), ("max", calc_max),
+                         ("skewness", calc_skewness), ("kurtosis", calc_kurtosis)):
             if on:
-                data[f"b{b}_{name}"] = st[key][:, j]
-    if tex_bands:
-        tx = texture_stats(img_data, segments, bands=tex_bands, start_label=start_label, n_labels=n, ctx=ctx)
+                data[f"b{b}_{name}"] = st[name][present, j]
+    tex_names = [(name, on) for name, on in (("contrast", calc_contrast), ("dissimilarity", calc_dissimilarity),
+                                             ("homogeneity", calc_homogeneity), ("ASM", calc_ASM), ("energy", calc_energy),
+                                             ("correlation", calc_correlation)) if on]
+    if calculate_textural and textural_bands and tex_names:
+        tx = texture_stats(img_data, labels, bands=textural_bands, start_label=start_label, n_labels=n, ctx=ctx)
         tx = {k: (v.cpu().numpy() if _is_torch(v) else v) for k, v in tx.items()}
-        for j, b in enumerate(tex_bands):
-            for name, on in (("contrast", calc_contrast), ("dissimilarity", calc_dissimilarity),
-                             ("homogeneity", calc_homogeneity), ("ASM", calc_ASM), ("energy", calc_energy),
-                             ("correlation", calc_correlation)):
-                if on:
-                    data[f"b{b}_{name}"] = tx[name][:, j]
-    return pd.DataFrame(data, columns=cols)
+        for j, b in enumerate(textural_bands):
+            for name, _ in tex_names:
+                data[f"b{b}_{name}"] = tx[name][present, j]
+    for c in cols:                                 # textural columns when calculate_textural=False, point-cloud columns: NaN
+        if c not in data and c != "geometry":
+            data[c] = np.full(n_rows, np.nan)
+    geoms = [None] * n_rows
+    crs = getattr(image, "crs", None)
+    if geometry:
+        if seg_table is not None and "geometry" in seg_table and len(seg_table) == n_rows:
+            geoms = list(seg_table["geometry"])
+        else:
+            from .polygons import polygonize
+            pt = polygonize(labels, affine_transformation=getattr(image, "affine_transformation", None),
+                            start_label=start_label, ctx=ctx)
+            if len(pt) != n_rows:
+                raise RuntimeError(f"polygoniser returned {len(pt)} polygons for {n_rows} labels")
+            geoms = pt.wkb()
+    data["geometry"] = geoms
+    df = pd.DataFrame(data, columns=cols)
+    if geometry:
+        try:                                       # the reference returns a GeoDataFrame; without its geo stack: WKB bytes
+            import geopandas as gpd
+            import shapely
+            df = gpd.GeoDataFrame(df.drop(columns="geometry"), geometry=list(shapely.from_wkb(geoms)), crs=crs)[cols]
+        except ImportError:
+            pass
+    df.attrs["crs"] = crs
+    return df

@@ -36,8 +36,24 @@ def _open_raster(path):
     return arr, abs(gt[1]), abs(gt[5])
 
 
+def write_segments_gpkg(labels, output_dir, affine_transformation=None, crs=None, ctx=None):
+    """``all_segments.to_file(output_dir/"segments.gpkg", driver="GPKG")`` (tiling.py:289-291) for a label raster with ids
+    1..N: polygons from the GPU polygoniser, columns ``geom`` / ``segment_id``, written with the standard library
+    (obia_amd.geopackage).  Returns the path."""
+    import os
+    from .geopackage import write_geopackage
+    from .polygons import polygonize
+    from .segmentation import _epsg_of
+    os.makedirs(output_dir, exist_ok=True)
+    pt = polygonize(labels, affine_transformation=affine_transformation, start_label=1, ctx=ctx)
+    path = os.path.join(output_dir, "segments.gpkg")
+    write_geopackage(path, pt.wkb(), {"segment_id": np.arange(1, len(pt) + 1)}, table="segments", srs_epsg=_epsg_of(crs))
+    return path
+
+
 def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method="slic", tile_size=200, buffer=30,
-                          crown_radius=5, pixel_size=None, white_order="raster", ctx=None, **kwargs):
+                          crown_radius=5, pixel_size=None, white_order="raster", affine_transformation=None, crs=None, ctx=None,
+                          **kwargs):
     """Tiled SLIC over a large raster.
 
     input_raster : path (GDAL), object with ``img_data``, (H,W,C) NumPy array, or CUDA tensor.
@@ -48,6 +64,10 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
         (tiling.py:126-135) and the side of the masked corner squares (buffer/2 map units, tiling.py:189).
     white_order  : "raster" (the reference's order of white tiles) or "parity" (even tile rows, then odd ones:
         the order of the multi-GPU driver, obia_amd.distributed).
+    output_dir   : when given, ``segments.gpkg`` is written there like the reference does (tiling.py:289-291; columns
+        geometry + segment_id), from either entry (NumPy array or CUDA tensor).  ``affine_transformation`` ([a, b, d, e,
+        xoff, yoff], obia ``Image.affine_transformation``; taken from the geotransform for paths, default: pixel size and
+        a north-up origin at (0, 0)) and ``crs`` ("EPSG:xxxx") place the polygons.
     kwargs       : SLIC keyword arguments (scikit-image names).  ``n_segments`` (which the reference
         cannot accept: duplicate keyword TypeError, tiling.py:126,137-143) is taken per full tile and
         scaled by the tile's valid area.
@@ -65,6 +85,10 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
         img, pw, ph = _open_raster(input_raster)
     else:
         img = input_raster.img_data if hasattr(input_raster, "img_data") else input_raster
+        if affine_transformation is None:
+            affine_transformation = getattr(input_raster, "affine_transformation", None)
+        if crs is None:
+            crs = getattr(input_raster, "crs", None)
     if isinstance(input_mask, str):
         m, _, _ = _open_raster(input_mask)
         input_mask = m[:, :, 0] != 0
@@ -106,6 +130,8 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
         out = torch.empty((H, W), dtype=torch.int32, device=x.device)
         _lib.check(lib.obia_tiled_slic_f32_dev(c.handle, x.data_ptr(), m.data_ptr() if m is not None else None, H, W, C,
                                                ctypes.byref(tp), ctypes.byref(params), out.data_ptr(), ctypes.byref(n_out)))
+        if output_dir is not None:
+            write_segments_gpkg(out, output_dir, affine_transformation or [pw, 0.0, 0.0, -ph, 0.0, 0.0], crs, ctx=c)
         return out, int(n_out.value)
     x = np.ascontiguousarray(img, dtype=np.float32)
     if x.ndim != 3:
@@ -121,7 +147,5 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
     _lib.check(lib.obia_tiled_slic_f32(c.handle, _lib.np_ptr(x), _lib.np_ptr(m), H, W, C, ctypes.byref(tp),
                                        ctypes.byref(params), _lib.np_ptr(out), ctypes.byref(n_out)))
     if output_dir is not None:
-        import os
-        os.makedirs(output_dir, exist_ok=True)
-        np.save(os.path.join(output_dir, "segments_labels.npy"), out)
+        write_segments_gpkg(out, output_dir, affine_transformation or [pw, 0.0, 0.0, -ph, 0.0, 0.0], crs, ctx=c)
     return out, int(n_out.value)

@@ -86,6 +86,69 @@ def test_objects_table_columns_follow_reference_order():
     assert stats_columns([0], [], calc_skewness=False, calc_kurtosis=False) == ["segment_id", "b0_mean", "b0_variance", "b0_min", "b0_max"]
 
 
+def test_objects_table_schema_equals_the_reference_source():
+    """create_objects' positional order, defaults and default column list against the reference's own source text
+    (obia/segmentation/segment_statistics.py:392-398 and :66-108), parsed with ast when /root/reference is present (it is
+    not on the GPU box; the expected values are also written out below)."""
+    import ast
+    import inspect
+    from obia_amd.statistics import create_objects, stats_columns
+    sig = inspect.signature(create_objects)
+    pos = [p.name for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    expected = ["segments", "image", "ept", "ept_srs", "spectral_bands", "textural_bands", "voxel_resolution",
+                "calculate_spectral", "calculate_textural", "calculate_structural", "calculate_radiometric",
+                "calc_mean", "calc_variance", "calc_min", "calc_max", "calc_skewness", "calc_kurtosis", "calc_contrast",
+                "calc_dissimilarity", "calc_homogeneity", "calc_ASM", "calc_energy", "calc_correlation", "calc_pai", "calc_fhd",
+                "calc_ch", "calc_mean_intensity", "calc_variance_intensity"]
+    assert pos == expected
+    defaults = {p.name: p.default for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD and p.default is not p.empty}
+    assert defaults["calculate_textural"] is True and defaults["calculate_structural"] is False and defaults["calc_pai"] is True
+    ref = "/root/reference/obia/segmentation/segment_statistics.py"
+    import os
+    if os.path.exists(ref):
+        fn = [n for n in ast.parse(open(ref).read()).body if isinstance(n, ast.FunctionDef) and n.name == "create_objects"][0]
+        names = [a.arg for a in fn.args.args]
+        dflt = [ast.literal_eval(d) for d in fn.args.defaults]
+        assert names == expected
+        assert dict(zip(names[len(names) - len(dflt):], dflt)) == defaults
+    # default columns for a 2-band raster: what segment() yields in the reference (segment.py:87-91 passes no textural flag)
+    cols = stats_columns([0, 1], [0, 1], calc_pai=True, calc_fhd=True, calc_ch=True, calc_mean_intensity=True,
+                         calc_variance_intensity=True, geometry=True)
+    assert cols == ["segment_id"] + [f"b{b}_{s}" for b in (0, 1) for s in ("mean", "variance", "min", "max", "skewness", "kurtosis")] \
+        + [f"b{b}_{s}" for b in (0, 1) for s in ("contrast", "dissimilarity", "homogeneity", "ASM", "energy", "correlation")] \
+        + ["pai", "fhd", "ch", "mean_intensity", "variance_intensity", "geometry"]
+
+
+def test_geopackage_round_trip(tmp_path):
+    """obia_amd.geopackage writes what tiling.py:291 writes through GDAL: a GeoPackage with `segments` (geometry +
+    segment_id).  Round trip of a polygon with a hole and a multipolygon; container magic, metadata rows, blob headers."""
+    import sqlite3
+    import struct
+    from obia_amd.geopackage import write_geopackage, read_geopackage, wkb_rings
+
+    def poly(rings):
+        b = struct.pack("<BII", 1, 3, len(rings))
+        for r in rings:
+            b += struct.pack("<I", len(r)) + np.asarray(r, "<f8").tobytes()
+        return b
+    sq = lambda x0, y0, s: [(x0, y0), (x0 + s, y0), (x0 + s, y0 + s), (x0, y0 + s), (x0, y0)]      # noqa: E731
+    a = poly([sq(0, 0, 10), sq(2, 2, 3)])
+    b = struct.pack("<BII", 1, 6, 2) + poly([sq(20, 0, 4)]) + poly([sq(30, 5, 2)])
+    path = write_geopackage(str(tmp_path / "segments.gpkg"), [a, b], {"segment_id": [1, 2], "b0_mean": [0.5, float("nan")]},
+                            srs_epsg=32610)
+    wkbs, cols, srs = read_geopackage(path)
+    assert wkbs == [a, b] and cols["segment_id"] == [1, 2] and cols["b0_mean"] == [0.5, None] and srs == 32610
+    assert [len(p) for p in wkb_rings(wkbs[1])] == [1, 1] and len(wkb_rings(wkbs[0])[0]) == 2
+    con = sqlite3.connect(path)
+    assert con.execute("PRAGMA application_id").fetchone()[0] == 0x47504B47
+    assert con.execute("SELECT min_x, min_y, max_x, max_y FROM gpkg_contents").fetchone() == (0.0, 0.0, 32.0, 10.0)
+    assert con.execute("SELECT count(*) FROM gpkg_spatial_ref_sys WHERE srs_id IN (-1, 0, 4326, 32610)").fetchone()[0] == 4
+    blob = con.execute("SELECT geom FROM segments WHERE fid = 2").fetchone()[0]
+    assert blob[:2] == b"GP" and struct.unpack_from("<i", blob, 4)[0] == 32610
+    assert struct.unpack_from("<4d", blob, 8) == (20.0, 32.0, 0.0, 7.0)
+    con.close()
+
+
 def test_oracle_tiler_properties(oracle):
     """The CPU restatement of the tile loops (test infrastructure): ids are 1..N, every segment is 4-connected,
     masked pixels stay 0, the crown rule sets the density."""

@@ -203,3 +203,30 @@ def test_widened_rows_without_any_label():
     tab = polygonize(lab, start_label=1)
     assert len(tab) == 0 and len(tab.ring_label) == 0 and tab.geojson_features() == []
     assert not slic_edge(lab).any()
+
+
+def test_coarse_segmentation_of_a_big_raster_keeps_64_bit_coordinate_sums():
+    """8192 x 8192 with n_segments=100: a cluster holds ~670 000 pixels and the sum of their row indices passes 2^32
+    (670 000 x 7 700).  The accumulator records carry n, sum_y and sum_x as separate 64-bit words; with a 32-bit sum_y the
+    centroids of the lower rows would land ~6 000 rows too high and the bottom of the raster would come out mislabelled.
+    Property: compactness 100 on a smooth image gives a near-regular 10 x 10 grid -- every segment's bounding box is about
+    one grid step wide and tall, its centre of mass sits in the middle of the box, and the sizes are within 25 % of the mean."""
+    from obia_amd.segmentation import slic
+    H = W = 8192
+    yy = torch.arange(H, device="cuda", dtype=torch.float32)[:, None]
+    xx = torch.arange(W, device="cuda", dtype=torch.float32)[None, :]
+    img = (torch.sin(xx / 700.0) * torch.cos(yy / 900.0)).unsqueeze(-1).contiguous()
+    lab = slic(img, n_segments=100, compactness=100.0, _normalize_bands=True)
+    n = int(lab.max().item())
+    assert n == 100 and int(lab.min().item()) == 1
+    S = 819.0
+    sizes = torch.bincount(lab.reshape(-1), minlength=n + 1)[1:].to(torch.float64)
+    assert float(sizes.min()) >= 0.75 * H * W / n and float(sizes.max()) <= 1.25 * H * W / n
+    rows = torch.arange(H, device="cuda", dtype=torch.float64)[:, None].expand(H, W)
+    sum_y = torch.zeros(n + 1, dtype=torch.float64, device="cuda").index_add_(0, lab.reshape(-1).to(torch.int64), rows.reshape(-1))[1:]
+    cy = (sum_y / sizes).cpu().numpy()
+    for v in range(1, n + 1):
+        ys = torch.nonzero((lab == v).any(dim=1)).reshape(-1)
+        y0, y1 = int(ys.min()), int(ys.max())
+        assert y1 - y0 <= 1.4 * S, f"segment {v} spans rows {y0}..{y1}"
+        assert abs(cy[v - 1] - 0.5 * (y0 + y1)) <= 0.15 * S

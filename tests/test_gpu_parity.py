@@ -357,10 +357,18 @@ def test_zonal_skewness_kurtosis_vs_scipy_golden(amd):
     np.testing.assert_allclose(st2["skewness"].cpu().numpy(), st["skewness"][:, [4, 1]], rtol=1e-12, equal_nan=True)
     np.testing.assert_allclose(st2["kurtosis"].cpu().numpy(), st["kurtosis"][:, [4, 1]], rtol=1e-12, equal_nan=True)
     # the objects table carries the columns in the reference's order (segment_statistics.py:66-75)
-    df = create_objects(lab, raw, spectral_bands=[0, 2])
+    # ... with the reference's defaults: GLCM columns of every band, the five point-cloud columns (NaN), geometry last
+    # (segment_statistics.py:96-108); one row per label that exists, segment_id 1..N (segment_boundaries.py:76)
+    df = create_objects(lab, raw, spectral_bands=[0, 2], geometry=False)
+    C = raw.shape[2]
     assert list(df.columns) == ["segment_id"] + [f"b{b}_{s}" for b in (0, 2)
-                                                  for s in ("mean", "variance", "min", "max", "skewness", "kurtosis")]
-    np.testing.assert_allclose(df["b2_skewness"].to_numpy(), st["skewness"][:, 2], rtol=1e-12, equal_nan=True)
+                                                  for s in ("mean", "variance", "min", "max", "skewness", "kurtosis")] \
+        + [f"b{b}_{t}" for b in range(C) for t in ("contrast", "dissimilarity", "homogeneity", "ASM", "energy", "correlation")] \
+        + ["pai", "fhd", "ch", "mean_intensity", "variance_intensity", "geometry"]
+    present = st["count"] > 0
+    assert list(df["segment_id"]) == list(range(1, int(present.sum()) + 1))
+    np.testing.assert_allclose(df["b2_skewness"].to_numpy(), st["skewness"][present, 2], rtol=1e-12, equal_nan=True)
+    assert df[["pai", "fhd", "ch", "mean_intensity", "variance_intensity"]].isna().all().all()
 
 
 def test_glcm_texture_vs_skimage_golden(amd, oracle):
@@ -387,7 +395,13 @@ def test_glcm_texture_vs_skimage_golden(amd, oracle):
     chk = glcm.texture_stats(raw, coarse, bands=[2, 0])
     for p in TEXTURE_PROPS:
         np.testing.assert_allclose(st2[p].cpu().numpy(), chk[p], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=p)
-    df = create_objects(lab, raw, spectral_bands=[0], textural_bands=[1], calculate_textural=True, calc_skewness=False,
-                        calc_kurtosis=False)
-    assert list(df.columns) == ["segment_id", "b0_mean", "b0_variance", "b0_min", "b0_max"] + [f"b1_{p}" for p in TEXTURE_PROPS]
-    np.testing.assert_allclose(df["b1_energy"].to_numpy(), st["energy"][:, 1], rtol=1e-12, equal_nan=True)
+    df = create_objects(lab, raw, spectral_bands=[0], textural_bands=[1], calc_skewness=False, calc_kurtosis=False,
+                        calc_pai=False, calc_fhd=False, calc_ch=False, calc_mean_intensity=False, calc_variance_intensity=False)
+    assert list(df.columns) == ["segment_id", "b0_mean", "b0_variance", "b0_min", "b0_max"] + [f"b1_{p}" for p in TEXTURE_PROPS] \
+        + ["geometry"]
+    from obia_amd.statistics import zonal_stats
+    present = zonal_stats(raw, lab)["count"] > 0
+    np.testing.assert_allclose(df["b1_energy"].to_numpy(), st["energy"][present, 1], rtol=1e-12, equal_nan=True)
+    # calculate_textural=False keeps the columns (the reference builds them from textural_bands, :466-471) and leaves them NaN
+    df2 = create_objects(lab, raw, spectral_bands=[0], textural_bands=[1], calculate_textural=False, geometry=False)
+    assert df2[[f"b1_{p}" for p in TEXTURE_PROPS]].isna().all().all() and len(df2) == len(df)
