@@ -6,13 +6,19 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on; i
   crown_radius=5, pixel size 0.5 m, all-ones mask, compactness=10)  +  zonal mean/var/min/max on all 8 bands.
 One "step" = that whole pipeline once, input already resident in HBM.  value = H*W / step time (Mpixel/s).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu]
-For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); every rank owns one
-16384-row slab (the N = 1 workload) of a (N*16384) x 16384 x 8 raster, and the slabs are segmented as ONE raster:
-halo rows and seam label rows travel by send/recv between neighbouring ranks (obia_amd/distributed.py), no collective
-on the data path.  The work per GPU is the same at every N, the N = 1 case included => "scaling": "weak".
-(White tile rows run in two parity classes there -- the order that lets neighbouring slabs work at the same time --
-so a rank segments four tile rows per batch instead of one.)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4] [--size S] [--no-cpu] [--no-side]
+For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); --gpus must equal WORLD_SIZE.
+  --config c3 (default): every rank owns one 16384-row slab (the N = 1 workload) of a (N*16384) x 16384 x 8 raster, and the
+      slabs are segmented as ONE raster: halo rows and seam label rows travel by send/recv between neighbouring ranks
+      (obia_amd/distributed.py), no collective on the data path.  The work per GPU is the same at every N, the N = 1 case
+      included => "scaling": "weak".  (White tile rows run in two parity classes there -- the order that lets neighbouring
+      slabs work at the same time -- so a rank segments four tile rows per batch instead of one.)
+  --config c4: BASELINE configs[3], the raster is ALWAYS 32768 x 32768 x 8 (tile 2048, overlap 64): N = 1 segments it whole
+      (34 GB of raster on one 288-GB GPU), N ranks take 32768/N rows each (8 GPUs: slabs of 4096 rows = 2 tile rows)
+      => "scaling": "strong"; this is the case north_star's ">= 6x at 8 GPUs" speaks of.
+Side legs at N = 1 (never `value`; --no-side skips them): the same workload at compactness 0.25 (the author's regime,
+notebooks/deepfor.ipynb:402 -- at compactness 10 on [0,1] features the result is nearly a grid), and BASELINE configs[4]
+(8192 x 8192 x 3 quickshift, kernel_size 5, max_dist 10).
 
 The JSON line carries `roofline` (dominant kernel = the SLIC colour sweep slic_assign_kernel<8,true,false>:
 algorithmic bytes (4*C + 4 = 36 B/pixel) x pixels per launch / launch time from HIP events on
@@ -48,6 +54,41 @@ def synth_raster(H, W, C, seed, device, row0=0):
             out[y0:y0 + h, :, c] = 400.0 * torch.sin(xx / (11 + 3 * c)) * torch.cos(yy / (13 + 2 * c)) + 1000 + 50 * c \
                 + 20.0 * torch.randn((h, W), device=device, generator=g)
     return out
+
+
+KERNEL_SOURCES = ("obia_amd/csrc/slic_sweep.hip", "obia_amd/csrc/slic.hpp", "obia_amd/csrc/slic.hip")
+
+
+def kernel_source_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def traffic_fields(args, C, world):
+    """roofline.traffic from profiles/r02_traffic.json (written by tools/traffic_json.py from two rocprofv3 --pmc passes of
+    this workload).  null unless the file was measured on exactly these kernel sources and this workload."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    none = {"traffic": None, "traffic_source": None}
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except Exception:
+        return none
+    same_src = t.get("kernel_source_sha256") == kernel_source_sha256()
+    wl = t.get("workload", {})
+    same_wl = (world == 1 and args.config == "c3" and wl.get("size") == args.size and wl.get("tile") == args.tile
+               and wl.get("buffer") == args.buffer and wl.get("bands") == C and abs(wl.get("compactness", -1) - args.compactness) < 1e-12)
+    if not (same_src and same_wl):
+        return dict(none, traffic_source=f"profiles/r02_traffic.json is for other {'sources' if not same_src else 'workload'} "
+                                         f"(measured at commit {t.get('commit')}): not reported")
+    k = t["kernels"]["slic_assign_colour"]
+    return {"traffic": int(round(k["bytes_per_launch"])),
+            "traffic_source": f"profiles/r02_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per launch, measured at commit {t.get('commit')} "
+                              f"on the same kernel sources ({k['bytes_per_pixel']:.1f} B/pixel vs 36 algorithmic)"}
 
 
 def cpu_baseline(C, tile, buffer_, crown_radius, pixel, compactness):
@@ -106,11 +147,19 @@ def main():
     ap.add_argument("--bands", type=int, default=8)
     ap.add_argument("--compactness", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-side", action="store_true", help="skip the side legs (exit_on_fixed_point, compactness 0.25, quickshift)")
+    ap.add_argument("--config", choices=("c3", "c4"), default="c3",
+                    help="c3: BASELINE configs[2] per GPU (weak scaling); c4: BASELINE configs[3], 32768^2 x 8 split over the ranks (strong)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # checked before anything touches the GPU: a bench keyed on --gpus must never report a run that did not shard
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}.  For N > 1 launch one rank per GPU:\n"
+                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: obia_amd has no CPU path")
     # OBIA_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE card (seam rows staged through
@@ -134,7 +183,15 @@ def main():
     from obia_amd.distributed import ShardedTiler
 
     C = args.bands
-    if world == 1:
+    if args.config == "c4":
+        W = Hg = 32768 if args.size == 16384 else args.size     # --size scales the case down for rehearsals
+        if Hg % (world * args.tile) != 0:
+            raise SystemExit(f"--config c4: {Hg} rows do not split into {world} slabs of whole {args.tile}-row tile rows")
+        H = Hg // world
+        row0 = rank * H
+        workload = (f"{Hg}x{W}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[3])"
+                    + (f", {world} slabs of {H} rows, seam exchange over RCCL send/recv" if world > 1 else ", whole raster on one GPU"))
+    elif world == 1:
         H = W = args.size
         workload = f"{H}x{W}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[2])"
         row0 = 0
@@ -153,7 +210,7 @@ def main():
         # copies nothing per call
         top, bot = ShardedTiler.halo_rows(rank, world, args.buffer)
         ext_img = torch.empty((top + H + bot, W, C), dtype=torch.float32, device=dev)
-        ext_img[top:top + H] = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
+        ext_img[top:top + H] = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)   # per-GPU slab seed = slab index
         ext_mask = torch.ones((top + H + bot, W), dtype=torch.uint8, device=dev)
         img, mask = ext_img[top:top + H], ext_mask[top:top + H]
     ctx = _lib.Context(gpu)
@@ -184,7 +241,7 @@ def main():
     def timed_fixed_point_leg():
         """Same workload with exit_on_fixed_point=True (bit-identical labels; sweeps of converged tiles skipped).
         Reported beside the headline, never as `value`: the headline runs every one of the 10 + 10 sweeps."""
-        if world != 1:
+        if world != 1 or args.no_side:
             return None
         kw2 = dict(kw, exit_on_fixed_point=True)
         lab_a, n_a = create_tiled_segments(img, input_mask=mask, **kw)
@@ -230,6 +287,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fp_leg = timed_fixed_point_leg()
+
+    def compactness_leg(c):
+        """The headline workload at another compactness (SURVEY 8d asks for 0.25, the author's regime, beside 10)."""
+        if world != 1 or args.no_side:
+            return None
+        kw2 = dict(kw, compactness=c)
+        create_tiled_segments(img, input_mask=mask, **kw2)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        a_ms = a_px = sw = 0.0
+        for _ in range(args.steps):
+            lab_c, n_c = create_tiled_segments(img, input_mask=mask, **kw2)
+            tt = ctx.timing()
+            a_ms += tt["assign_ms"]; a_px += tt["assign_px"]; sw += tt["sweeps"]
+            zonal_stats(img, lab_c, n_labels=n_c, ctx=ctx)
+        torch.cuda.synchronize()
+        d = (time.time() - t1) / args.steps
+        ach = (a_px * (4 * C + 4)) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+        return {"compactness": c, "value": round(float(H) * W / d / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(d * 1e3, 3),
+                "segments": int(n_c), "sweep_avg_launch_ms": round(a_ms / max(1.0, sw), 4),
+                "sweep_roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
+
+    def quickshift_leg():
+        """BASELINE configs[4]: 8192 x 8192 x 3, quickshift(kernel_size=5, max_dist=10), tie noise drawn on the device."""
+        if world != 1 or args.no_side:
+            return None
+        from obia_amd.segmentation import quickshift
+        S = 8192 if args.size >= 8192 else args.size
+        rgb = synth_raster(S, S, 3, seed=5, device=dev)
+        mn, mx = rgb.amin(dim=(0, 1)), rgb.amax(dim=(0, 1))
+        rgb = ((rgb - mn) / (mx - mn)).contiguous()      # values in [0, 1], treated as sRGB (SURVEY 8d)
+        quickshift(rgb, kernel_size=5, max_dist=10, ratio=1.0, rng="device", ctx=ctx)
+        torch.cuda.synchronize()
+        reps = max(1, min(args.steps, 3))
+        t1 = time.time()
+        for _ in range(reps):
+            ql = quickshift(rgb, kernel_size=5, max_dist=10, ratio=1.0, rng="device", ctx=ctx)
+        torch.cuda.synchronize()
+        d = (time.time() - t1) / reps
+        return {"workload": f"{S}x{S}x3 quickshift(kernel_size=5, max_dist=10) (BASELINE configs[4])", "value": round(S * S / d / 1e6, 2),
+                "unit": "Mpixel/s", "ms_per_call": round(d * 1e3, 2), "segments": int(ql.max().item()) + 1, "dtype": "f64"}
+
+    c025_leg = compactness_leg(0.25) if abs(args.compactness - 0.25) > 1e-9 else None
+    qs_leg = quickshift_leg()
     ms_per_step = dt / args.steps * 1e3
     total_px = float(H) * W * world
     value = total_px / (dt / args.steps) / 1e6
@@ -241,7 +342,8 @@ def main():
         out = {
             "metric": "Mpixel/s (SLIC+zonal feats) on 16384²×8-band; achieved HBM GB/s fraction",
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,
                        "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
@@ -249,10 +351,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-                         # passes, gfx950 correction): 48.7 B/pixel measured in round 1 for C = 8 (profiles/r01_traffic.md)
-                         "traffic": round(48.7 * assign_px / max(1.0, sweeps)) if C == 8 else None,
-                         "traffic_source": "profiles/r01_traffic.md (PMC run of this command, not live)",
+                         # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
+                         # gfx950 correction; tools/traffic_json.py).  Dated, not live: only reported when the kernel sources
+                         # are byte-identical to the ones the counters were collected on and the workload is the same.
+                         **traffic_fields(args, C, world),
                          "bytes_per_pixel": bytes_per_px, "launches": int(sweeps), "avg_launch_ms": round(avg_launch_ms, 4),
                          "pixels_per_launch_avg": round(assign_px / max(1.0, sweeps), 1)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in parts.items()},
@@ -262,6 +364,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["with_exit_on_fixed_point"] = fp_leg
+        out["compactness_0.25"] = c025_leg
+        out["quickshift"] = qs_leg
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
