@@ -29,7 +29,8 @@ import torch.distributed as dist
 from . import _lib
 from .segmentation import make_params
 
-CODE_SHIFT = 24
+CODE_SHIFT = 24                      # a segment travels as the int32 code (owner_rank + 1) << 24 | owner_local_id
+ID_MASK = (1 << CODE_SHIFT) - 1
 HUGE = 0xFFFFFFFF
 
 
@@ -46,8 +47,15 @@ class HipTilerEngine:
                                   max_num_iter=slic_kwargs.get("max_num_iter", 10),
                                   convert2lab=slic_kwargs.get("convert2lab", None),
                                   min_size_factor=slic_kwargs.get("min_size_factor", 0.5),
-                                  max_size_factor=slic_kwargs.get("max_size_factor", 3), start_label=1, normalize_bands=True,
+                                  max_size_factor=slic_kwargs.get("max_size_factor", 3),
+                                  slic_zero=slic_kwargs.get("slic_zero", False), start_label=1, normalize_bands=True,
                                   exit_on_fixed_point=slic_kwargs.get("exit_on_fixed_point", False))
+        if not slic_kwargs.get("enforce_connectivity", True):
+            raise NotImplementedError("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)")
+        unknown = [k for k in slic_kwargs if k not in ("n_segments", "compactness", "max_num_iter", "convert2lab", "min_size_factor",
+                                                      "max_size_factor", "slic_zero", "exit_on_fixed_point", "enforce_connectivity")]
+        if unknown:
+            raise TypeError(f"slic() got an unexpected keyword argument '{unknown[0]}'")
         self.tp = _lib.TilingParams()
         self.tp.tile_size, self.tp.buffer, self.tp.white_order = int(tile_size), int(buffer), 1
         self.tp.crown_radius, self.tp.pixel_width, self.tp.pixel_height = float(crown_radius), float(pixel_size[0]), float(pixel_size[1])
@@ -97,7 +105,13 @@ def _p2p(ops):
 
 
 class ShardedTiler:
-    """One rank of the sharded driver.  ``slab`` / ``mask_slab``: this rank's rows (whole tile rows)."""
+    """One rank of the sharded driver.  ``slab`` / ``mask_slab``: this rank's rows (whole tile rows).
+
+    Bookkeeping of foreign segments (the neighbours' segments that reach into my halo rows) is dense and lives on the
+    device: ``fmap[owner]`` maps the owner's local id to my local id, ``code_of`` maps my local ids back to wire codes.
+    Importing a seam therefore is a few gathers / scatters and ONE 8-byte read-back (how many new ids to reserve in the
+    engine); there is no sort, search or ``unique`` on the data path and the kill lists are built and applied without
+    any host round trip."""
 
     @staticmethod
     def halo_rows(rank, world, buffer):
@@ -113,6 +127,10 @@ class ShardedTiler:
         if self.world > 127:
             raise ValueError("at most 127 ranks (segment codes keep the owner in 7 bits)")
         self.T, self.B, self.hb = int(tile_size), int(buffer), int(buffer) + 1
+        if self.world > 1 and self.T <= 2 * self.B + 1:
+            # the seam protocol needs a passive rank's second-to-last tile row to stay clear of the boundary rows the
+            # active rank sends back, and the white windows of one parity class not to see each other
+            raise ValueError(f"sharded driver: tile_size ({self.T}) must exceed 2 * buffer + 1 ({2 * self.B + 1})")
         self.R = int(tile_rows_per_rank)
         self.Hg = int(global_rows)
         self.row_lo = self.rank * self.R * self.T
@@ -156,11 +174,16 @@ class ShardedTiler:
         self.row0_ext = self.row_lo - self.top
         factory = engine_factory or (lambda img, m, Hg, row0, extra: HipTilerEngine(
             img, m, Hg, row0, tile_size, buffer, crown_radius, pixel_size, slic_kwargs, extra, ctx=ctx))
+        # room for the foreign segments of three imports per seam (one per parity class it is active in, the final refresh
+        # for the statistics): every imported segment has a pixel in the hb boundary rows
         self.engine = factory(ext.contiguous(), mext.contiguous(), self.Hg, self.row0_ext, 16 * W + 1024)
         self.G = self.engine.G
-        # foreign segments: sorted codes and their local ids; batches of contiguous local ids for re-sizing
-        self.f_codes = torch.empty((0,), dtype=torch.int64, device=self.G.device)
-        self.f_ids = torch.empty((0,), dtype=torch.int64, device=self.G.device)
+        gdev = self.G.device
+        self.code_of = torch.zeros((1 << 16,), dtype=torch.int32, device=gdev)   # my local id -> wire code (0: one of my own)
+        self.fmap = {}        # owner rank -> int32 map: the owner's local id -> my local id (0: not imported yet)
+        self.f_batches = []   # (owner rank, first local id, count): contiguous ranges of imported ids
+        self.stats = {"imports": 0, "foreign_ids": 0, "kills_sent_up": 0, "kills_sent_down": 0}   # host-side counters (tests)
+        self._check_ids()
 
     # ---- communication helpers ---------------------------------------------------------------------------------
     def _to_wire(self, t):
@@ -185,75 +208,88 @@ class ShardedTiler:
             ext[ext.shape[0] - self.bot:] = bufs["down"].to(ext.device)
 
     # ---- id codes --------------------------------------------------------------------------------------------------
-    def _codes_of(self, ids):
-        """local ids -> codes"""
-        ids = ids.to(torch.int64)
-        codes = torch.where(ids > 0, ids + ((self.rank + 1) << CODE_SHIFT), torch.zeros_like(ids))
-        if self.f_ids.numel():
-            order = torch.argsort(self.f_ids)
-            sid, scode = self.f_ids[order], self.f_codes[order]
-            pos = torch.searchsorted(sid, ids.reshape(-1)).clamp(max=sid.numel() - 1).reshape(ids.shape)
-            hit = sid[pos] == ids
-            codes = torch.where(hit, scode[pos], codes)
-        return codes
+    def _check_ids(self):
+        """local ids must fit the 24-bit field of the wire codes (host integer, no device round trip)"""
+        nid = int(self.engine.next_id())
+        if nid >= (1 << CODE_SHIFT):
+            raise RuntimeError(f"rank {self.rank}: {nid} provisional segment ids do not fit the {CODE_SHIFT}-bit id field of the "
+                               "seam codes: use smaller slabs (more ranks) or larger segments")
+        if nid > self.code_of.numel():
+            grown = torch.zeros((max(nid, 2 * self.code_of.numel()),), dtype=torch.int32, device=self.code_of.device)
+            grown[:self.code_of.numel()] = self.code_of
+            self.code_of = grown
+        return nid
 
-    def _ids_of(self, codes):
-        """codes -> local ids, registering unknown foreign codes"""
+    def _codes_of(self, ids):
+        """local ids -> int32 wire codes"""
+        self._check_ids()
+        ids = ids.to(torch.int64)
+        c = self.code_of[ids]
+        own = (ids + ((self.rank + 1) << CODE_SHIFT)).to(torch.int32)
+        return torch.where(c != 0, c, torch.where(ids > 0, own, torch.zeros_like(own)))
+
+    def _ids_of(self, codes, owners):
+        """int32 wire codes -> local ids; foreign codes not seen before get local ids (one contiguous range per owner,
+        reserved in the engine).  ``owners``: the ranks whose segments can occur (the sender and, through it, nobody
+        else: a slab is taller than a window's reach)."""
         codes = codes.to(torch.int64)
-        own = (codes >> CODE_SHIFT) == (self.rank + 1)
-        ids = torch.where(own, codes & ((1 << CODE_SHIFT) - 1), torch.zeros_like(codes))
-        foreign = (codes > 0) & ~own
-        if foreign.any():
-            uniq = torch.unique(codes[foreign])
-            if self.f_codes.numel():
-                pos = torch.searchsorted(self.f_codes, uniq).clamp(max=self.f_codes.numel() - 1)
-                known = self.f_codes[pos] == uniq
-            else:
-                known = torch.zeros_like(uniq, dtype=torch.bool)
-            new = uniq[~known]
-            if new.numel():
-                first = self.engine.next_id()
-                new_ids = torch.arange(first, first + new.numel(), device=codes.device, dtype=torch.int64)
-                self.engine.set_segments(first, torch.full_like(new_ids, HUGE))   # reserves the ids; sizes follow
-                allc = torch.cat([self.f_codes, new])
-                alli = torch.cat([self.f_ids, new_ids])
-                order = torch.argsort(allc)
-                self.f_codes, self.f_ids = allc[order], alli[order]
-            pos = torch.searchsorted(self.f_codes, codes.reshape(-1)).clamp(max=self.f_codes.numel() - 1).reshape(codes.shape)
-            ids = torch.where(foreign, self.f_ids[pos], ids)
+        their = codes & ID_MASK
+        owner = (codes >> CODE_SHIFT) - 1
+        ids = torch.where(owner == self.rank, their, torch.zeros_like(their))
+        for nb in owners:
+            sel = (owner == nb) & (codes > 0)
+            fm = self.fmap.get(nb)
+            if fm is None:
+                fm = self.fmap[nb] = torch.zeros((1 << CODE_SHIFT,), dtype=torch.int32, device=self.G.device)
+            t = torch.where(sel, their, torch.zeros_like(their))            # index 0 is a dummy entry
+            known = fm[t] != 0
+            flag = torch.zeros_like(fm)
+            flag.index_put_((torch.where(sel & ~known, t, torch.zeros_like(t)).reshape(-1),),
+                            torch.ones((), dtype=torch.int32, device=fm.device))
+            flag[0] = 0
+            rank_in_new = torch.cumsum(flag, 0, dtype=torch.int32)
+            n_new = int(rank_in_new[-1].item())                             # the one read-back of an import
+            if n_new:
+                first = self._check_ids()
+                # reserve the range in the engine; sizes follow in _refresh_foreign_sizes
+                self.engine.set_segments(first, torch.full((n_new,), HUGE, dtype=torch.int64, device=self.G.device))
+                fm = self.fmap[nb] = torch.where(flag != 0, rank_in_new + (first - 1), fm)
+                self._check_ids()
+                # codes of the new ids (rank order == ascending ids of the owner); entries that are not new land on the dummy id 0
+                their_all = torch.arange(fm.numel(), dtype=torch.int32, device=fm.device)
+                self.code_of.index_put_((torch.where(flag != 0, fm, torch.zeros_like(fm)).to(torch.int64),),
+                                        torch.where(flag != 0, their_all + ((nb + 1) << CODE_SHIFT), torch.zeros_like(their_all)))
+                self.code_of[0] = 0
+                self.f_batches.append((nb, first, n_new))
+                self.stats["foreign_ids"] += n_new
+            ids = torch.where(sel, fm[t].to(torch.int64), ids)
+        self.stats["imports"] += 1
         return ids
+
+    def _foreign_ids(self, owner=None):
+        """all local ids of imported segments (of one owner), ascending"""
+        rng = [torch.arange(f, f + c, device=self.G.device) for nb, f, c in self.f_batches if owner is None or nb == owner]
+        return torch.cat(rng) if rng else torch.empty((0,), dtype=torch.int64, device=self.G.device)
 
     def _refresh_foreign_sizes(self):
         """pixel counts of the foreign segments as seen locally; a segment on the outermost halo row continues
         beyond what this rank can see: it can never be `within` one of its windows"""
-        if not self.f_ids.numel():
+        if not self.f_batches:
             return
         G = self.G
         span = 2 * self.hb + self.B + 2
-        rows = []
+        rows, outer = [], []
         if self.top:
-            rows.append(G[:span].to(torch.int64))
+            rows.append(G[:span])
+            outer.append(G[0])
         if self.bot:
-            rows.append(G[G.shape[0] - span:].to(torch.int64))
-        flat = torch.cat([r.reshape(-1) for r in rows])
-        nmax = int(self.engine.next_id())
-        counts = torch.bincount(flat.clamp(min=0), minlength=nmax)[:nmax]
-        outer = []
-        if self.top:
-            outer.append(G[0].to(torch.int64))
-        if self.bot:
-            outer.append(G[-1].to(torch.int64))
-        edge = torch.unique(torch.cat(outer))
-        edge = edge[edge > 0]
-        counts[edge] = HUGE
-        ids_sorted = torch.sort(self.f_ids).values
-        # contiguous runs of ids -> one set_segments call each
-        brk = torch.nonzero(ids_sorted[1:] != ids_sorted[:-1] + 1).reshape(-1) + 1
-        starts = [0] + brk.tolist()
-        ends = brk.tolist() + [ids_sorted.numel()]
-        for a, b in zip(starts, ends):
-            first = int(ids_sorted[a])
-            self.engine.set_segments(first, counts[first:first + (b - a)])
+            rows.append(G[G.shape[0] - span:])
+            outer.append(G[-1])
+        nmax = self._check_ids()
+        counts = torch.bincount(torch.cat([r.reshape(-1) for r in rows]).to(torch.int64).clamp(min=0), minlength=nmax)[:nmax]
+        counts.index_fill_(0, torch.cat(outer).to(torch.int64).clamp(min=0), HUGE)
+        for nb, first, n in self.f_batches:
+            self.engine.set_segments(first, counts[first:first + n])
 
     # ---- one parity class of white tile rows -------------------------------------------------------------------
     def _seam_roles(self, cls):
@@ -270,74 +306,82 @@ class ShardedTiler:
     def _white_class(self, cls):
         au, pu, ad, pd = self._seam_roles(cls)
         hb, top, Hs = self.hb, self.top, self.Hs
-        # 1. passive sides send their boundary label rows (codes); active sides import them into their halo
+        wdev = "cpu" if self.cpu_comm else self.G.device
+        # 1. passive sides send their boundary label rows (int32 codes); active sides import them into their halo
         ops, rbuf = [], {}
         if pu:
             ops.append(dist.P2POp(dist.isend, self._to_wire(self._codes_of(self.G[top:top + hb])), self.rank - 1, self.group))
         if pd:
             ops.append(dist.P2POp(dist.isend, self._to_wire(self._codes_of(self.G[top + Hs - hb:top + Hs])), self.rank + 1, self.group))
         if au:
-            rbuf["up"] = torch.empty((hb, self.W), dtype=torch.int64, device="cpu" if self.cpu_comm else self.G.device)
+            rbuf["up"] = torch.empty((hb, self.W), dtype=torch.int32, device=wdev)
             ops.append(dist.P2POp(dist.irecv, rbuf["up"], self.rank - 1, self.group))
         if ad:
-            rbuf["down"] = torch.empty((hb, self.W), dtype=torch.int64, device="cpu" if self.cpu_comm else self.G.device)
+            rbuf["down"] = torch.empty((hb, self.W), dtype=torch.int32, device=wdev)
             ops.append(dist.P2POp(dist.irecv, rbuf["down"], self.rank + 1, self.group))
         _p2p(ops)
         if au:
-            self.G[:top] = self._ids_of(rbuf["up"].to(self.G.device)).to(self.G.dtype)
+            self.G[:top] = self._ids_of(rbuf["up"].to(self.G.device), (self.rank - 1,)).to(self.G.dtype)
         if ad:
-            self.G[top + Hs:] = self._ids_of(rbuf["down"].to(self.G.device)).to(self.G.dtype)
+            self.G[top + Hs:] = self._ids_of(rbuf["down"].to(self.G.device), (self.rank + 1,)).to(self.G.dtype)
         if au or ad:
             self._refresh_foreign_sizes()
         # 2. the pass itself: every tile row of this parity in my slab
         tr_lo = self.rank * self.R
         self.engine.run(True, tr_lo, tr_lo + (-(-Hs // self.T)), cls)
-        # 3. active sides send the halo rows back (+ one extra row listing the neighbour's segments they dropped:
-        #    [count, code, code, ...]); the owner overwrites its boundary rows and clears those segments
+        self._check_ids()
+        # 3. active sides send the halo rows back, followed by hb rows that list the neighbour's segments they dropped
+        #    ([count, code, code, ...]: every imported segment has a pixel in the hb rows, so the list always fits);
+        #    the owner overwrites its boundary rows and clears those segments
         ops, rbuf = [], {}
-        wdev = "cpu" if self.cpu_comm else self.G.device
         if au:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[:top], self.rank - 1)), self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[:top], self.rank - 1, "kills_sent_up")), self.rank - 1, self.group))
         if ad:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[top + Hs:], self.rank + 1)), self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[top + Hs:], self.rank + 1, "kills_sent_down")), self.rank + 1, self.group))
         if pu:
-            rbuf["up"] = torch.empty((hb + 1, self.W), dtype=torch.int64, device=wdev)
+            rbuf["up"] = torch.empty((2 * hb, self.W), dtype=torch.int32, device=wdev)
             ops.append(dist.P2POp(dist.irecv, rbuf["up"], self.rank - 1, self.group))
         if pd:
-            rbuf["down"] = torch.empty((hb + 1, self.W), dtype=torch.int64, device=wdev)
+            rbuf["down"] = torch.empty((2 * hb, self.W), dtype=torch.int32, device=wdev)
             ops.append(dist.P2POp(dist.irecv, rbuf["down"], self.rank + 1, self.group))
         _p2p(ops)
         if pu:
             buf = rbuf["up"].to(self.G.device)
-            self.G[top:top + hb] = self._ids_of(buf[:hb]).to(self.G.dtype)
-            self._apply_kills(buf[hb])
+            self.G[top:top + hb] = self._ids_of(buf[:hb], (self.rank - 1,)).to(self.G.dtype)
+            self._apply_kills(buf[hb:])
         if pd:
             buf = rbuf["down"].to(self.G.device)
-            self.G[top + Hs - hb:top + Hs] = self._ids_of(buf[:hb]).to(self.G.dtype)
-            self._apply_kills(buf[hb])
+            self.G[top + Hs - hb:top + Hs] = self._ids_of(buf[:hb], (self.rank + 1,)).to(self.G.dtype)
+            self._apply_kills(buf[hb:])
 
-    def _rows_with_kills(self, rows, owner_rank):
-        """codes of `rows` plus one extra row [count, codes of owner_rank's segments that I dropped in this pass]"""
-        out = torch.zeros((rows.shape[0] + 1, self.W), dtype=torch.int64, device=self.G.device)
-        out[:rows.shape[0]] = self._codes_of(rows)
-        if self.f_ids.numel():
-            alive = self.engine.get_alive(self.engine.next_id()).to(torch.bool)
-            mine = (self.f_codes >> CODE_SHIFT) == (owner_rank + 1)
-            dead = mine & ~alive[self.f_ids]
-            codes = self.f_codes[dead]
-            if codes.numel() >= self.W:
-                raise RuntimeError("kill list longer than a raster row")
-            out[-1, 0] = codes.numel()
-            out[-1, 1:1 + codes.numel()] = codes
+    def _rows_with_kills(self, rows, owner_rank, stat):
+        """int32 codes of `rows` followed by as many rows again holding [count, codes of owner_rank's segments that I dropped
+        in this pass, 0, ...]; built on the device without a host round trip (compaction by prefix sum)"""
+        nr = rows.shape[0]
+        out = torch.zeros((2 * nr, self.W), dtype=torch.int32, device=self.G.device)
+        out[:nr] = self._codes_of(rows)
+        fid = self._foreign_ids(owner_rank)
+        if fid.numel():
+            alive = self.engine.get_alive(self._check_ids()).to(torch.bool)
+            dead = ~alive[fid]
+            pos = torch.cumsum(dead.to(torch.int64), 0)                     # 1-based slot of every dropped segment
+            kill = out[nr:].reshape(-1)
+            # every imported segment owns a pixel of the nr x W rows: the list cannot outgrow them; live entries land on slot 0,
+            # which then takes the count
+            kill.index_put_((torch.where(dead, pos, torch.zeros_like(pos)),), torch.where(dead, self.code_of[fid], torch.zeros_like(self.code_of[fid])))
+            kill[0] = pos[-1].to(torch.int32)
+            if stat in self.stats and self.G.device.type == "cpu":      # host-side counter for the CPU protocol tests only
+                self.stats[stat] += int(pos[-1])
         return out
 
-    def _apply_kills(self, row):
-        n = int(row[0].item())
-        if n == 0:
-            return
-        ids = (row[1:1 + n] & ((1 << CODE_SHIFT) - 1)).to(torch.int64)
-        alive = self.engine.get_alive(self.engine.next_id())
-        alive[ids] = 0
+    def _apply_kills(self, rows):
+        """clear the alive flag of my segments a neighbour dropped (rows: [count, code, ..., 0, ...]); no host round trip:
+        unused entries are 0 and land on the dummy id 0"""
+        flat = rows.reshape(-1).to(torch.int64)
+        ids = flat & ID_MASK
+        ids[0] = 0                                                        # the count is not an id
+        alive = self.engine.get_alive(self._check_ids())
+        alive.index_fill_(0, ids, 0)
         self.engine.set_alive(alive)
 
     def run(self):
@@ -345,6 +389,7 @@ class ShardedTiler:
         tr_lo = self.rank * self.R
         ntr = -(-self.Hs // self.T)
         self.engine.run(False, tr_lo, tr_lo + ntr, -1)          # pass 1: black tiles, no communication
+        self._check_ids()
         self._white_class(0)
         self._white_class(1)
         labels, n = self._global_labels()
@@ -353,12 +398,13 @@ class ShardedTiler:
     def _number_segments(self):
         """ids 1..N over all ranks: rank offsets by all_gather of the alive counts, local order = creation order.
         Returns (lut over local ids -> global id, newid of my own segments, N)."""
-        nid = int(self.engine.next_id())
+        nid = self._check_ids()
         alive = self.engine.get_alive(nid).to(torch.bool)
         alive[0] = False
         own = alive.clone()
-        if self.f_ids.numel():
-            own[self.f_ids] = False
+        fid = self._foreign_ids()
+        if fid.numel():
+            own[fid] = False
         newid = torch.cumsum(own.to(torch.int64), 0) * own.to(torch.int64)        # 1-based rank among my alive segments
         n_alive = int(own.sum().item())
         cdev = "cpu" if self.cpu_comm else self.G.device
@@ -380,25 +426,17 @@ class ShardedTiler:
         for nb, t in rb.items():
             tables[nb] = t.to(self.G.device)
         lut = torch.where(own, newid + offset[self.rank], torch.zeros_like(newid))
-        if self.f_ids.numel():
-            owner = (self.f_codes >> CODE_SHIFT) - 1
-            lid = self.f_codes & ((1 << CODE_SHIFT) - 1)
-            g = torch.zeros_like(lid)
-            for nb, t in tables.items():
-                if nb == self.rank:
-                    continue
-                sel = owner == nb
-                if sel.any():
-                    v = t[lid[sel]]
-                    g[sel] = torch.where(v > 0, v + offset[nb], torch.zeros_like(v))
-            lut[self.f_ids] = torch.where(alive[self.f_ids], g, torch.zeros_like(g))
+        for nb, first, n in self.f_batches:
+            their = (self.code_of[first:first + n].to(torch.int64)) & ID_MASK
+            v = tables[nb][their]
+            g = torch.where(v > 0, v + offset[nb], torch.zeros_like(v))
+            lut[first:first + n] = torch.where(alive[first:first + n], g, torch.zeros_like(g))
         return lut.to(torch.int32), newid.to(torch.int32), sum(counts)
 
     def _global_labels(self):
         lut, newid, n = self._number_segments()
         self._newid = newid
         Gs = self.G[self.top:self.top + self.Hs]
-        assert int(Gs.max().item()) < lut.numel() and int(Gs.min().item()) >= 0
         return lut[Gs.to(torch.int64)], n
 
     def owned_labels(self):
@@ -408,22 +446,22 @@ class ShardedTiler:
         more exchange of boundary label rows so that the halo reflects the neighbours' final state."""
         top, Hs, hb = self.top, self.Hs, self.hb
         # refresh my halo label rows from the neighbours' final boundary rows (codes on the wire)
-        ext_rows = torch.zeros((self.G.shape[0], self.W), dtype=torch.int64, device=self.G.device)
+        ext_rows = torch.zeros((self.G.shape[0], self.W), dtype=torch.int32, device=self.G.device)
         send_top = self._codes_of(self.G[top:top + hb])
         send_bot = self._codes_of(self.G[top + Hs - hb:top + Hs])
         self._exchange_rows(ext_rows, send_top=send_top, send_bot=send_bot)
         if self.top:
-            self.G[:top] = self._ids_of(ext_rows[:top]).to(self.G.dtype)
+            self.G[:top] = self._ids_of(ext_rows[:top], (self.rank - 1,)).to(self.G.dtype)
         if self.bot:
-            self.G[top + Hs:] = self._ids_of(ext_rows[top + Hs:]).to(self.G.dtype)
+            self.G[top + Hs:] = self._ids_of(ext_rows[top + Hs:], (self.rank + 1,)).to(self.G.dtype)
         # dense ids of my own alive segments (set by run()); foreign ones -> 0: their owner counts them.  The halo
         # refresh above may have registered foreign segments that did not exist when run() numbered mine.
-        nid = int(self.engine.next_id())
+        nid = self._check_ids()
         newid = torch.zeros((nid,), dtype=torch.int32, device=self.G.device)
         newid[:self._newid.numel()] = self._newid
-        if self.f_ids.numel():
-            newid[self.f_ids] = 0
-        assert int(self.G.max().item()) < nid and int(self.G.min().item()) >= 0
+        fid = self._foreign_ids()
+        if fid.numel():
+            newid[fid] = 0
         dense = newid[self.G.to(torch.int64)]
         return self.engine.img if hasattr(self.engine, "img") else None, dense, int(newid.max().item()) if newid.numel() else 0
 

@@ -51,6 +51,20 @@ class OracleEngine:
                 self.t.alive[g] = bool(alive[g])
 
 
+def make_mask(H, W, mode):
+    """mode True / "disc": a disc; "seam": a disc with rectangles cut out that empty whole tiles on both sides of slab seams"""
+    if not mode:
+        return None
+    yy, xx = np.mgrid[0:H, 0:W]
+    m = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (0.48 * max(H, W)) ** 2)
+    if mode == "seam":
+        m = np.ones((H, W), bool)
+        m[60:160, 0:55] = False          # swallows tiles above and below the first seam (row 100) in the first tile column
+        m[180:215, 100:170] = False      # a band across the second seam (row 200)
+        m[290:300, :] = False            # the last rows of a slab: the seam at row 300 only has segments on one side
+    return m
+
+
 def _worker(rank, world, port, H, W, C, R, kw, mask_on, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -58,19 +72,18 @@ def _worker(rank, world, port, H, W, C, R, kw, mask_on, out):
     try:
         from obia_amd.distributed import create_tiled_segments_sharded
         img = synth(H, W, C)
-        mask = None
-        if mask_on:
-            yy, xx = np.mgrid[0:H, 0:W]
-            mask = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (0.48 * max(H, W)) ** 2)
+        mask = make_mask(H, W, mask_on)
         T = kw["tile_size"]
         lo, hi = rank * R * T, min(H, (rank + 1) * R * T)
         slab = torch.from_numpy(img[lo:hi].copy())
         mslab = None if mask is None else torch.from_numpy(mask[lo:hi].astype(np.uint8))
         ekw = dict(kw)
-        labels, n = create_tiled_segments_sharded(
-            slab, mslab, global_rows=H, tile_rows_per_rank=R, tile_size=T, buffer=kw["buffer"],
-            engine_factory=lambda im, m, Hg, row0, extra: OracleEngine(im, m, Hg, row0, ekw))
+        from obia_amd.distributed import ShardedTiler
+        t = ShardedTiler(slab, mslab, H, R, T, kw["buffer"], engine_factory=lambda im, m, Hg, row0, extra: OracleEngine(im, m, Hg, row0, ekw))
+        labels, n = t.run()
         np.save(os.path.join(out, f"lab{rank}.npy"), labels.numpy())
+        np.save(os.path.join(out, f"stats{rank}.npy"), np.array([t.stats["kills_sent_up"], t.stats["kills_sent_down"],
+                                                                  t.stats["foreign_ids"], t.stats["imports"]]))
         if rank == 0:
             np.save(os.path.join(out, "n.npy"), np.array([n]))
     finally:
@@ -85,10 +98,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,H,W,R,mask_on", [(2, 200, 230, 2, False), (2, 240, 170, 2, True), (3, 300, 150, 1, False)])
+@pytest.mark.parametrize("world,H,W,R,mask_on", [(2, 200, 230, 2, False), (2, 240, 170, 2, True), (3, 300, 150, 1, False),
+                                                 (4, 400, 170, 2, "seam")])
 def test_sharded_equals_single_process_parity_order(tmp_path, oracle, world, H, W, R, mask_on):
+    """world 4: two tile rows per rank, a mask that empties tiles on both sides of seams, segments dropped across seams in
+    both directions (the kill lists travel up AND down) -- still exactly the single-process partition."""
     from oracle import tiler
-    kw = dict(tile_size=50 if world == 2 and not mask_on else 60 if mask_on else 100, buffer=8, crown_radius=3,
+    kw = dict(tile_size=50 if (world == 2 and not mask_on) or world == 4 else 60 if mask_on else 100, buffer=8, crown_radius=3,
               pixel_size=(1.0, 1.0), compactness=10.0)
     T = kw["tile_size"]
     assert -(-H // T) <= world * R
@@ -96,10 +112,7 @@ def test_sharded_equals_single_process_parity_order(tmp_path, oracle, world, H, 
     lab = np.concatenate([np.load(tmp_path / f"lab{r}.npy") for r in range(world)], 0)
     n = int(np.load(tmp_path / "n.npy")[0])
     img = synth(H, W, 3)
-    mask = None
-    if mask_on:
-        yy, xx = np.mgrid[0:H, 0:W]
-        mask = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (0.48 * max(H, W)) ** 2)
+    mask = make_mask(H, W, mask_on)
     ref, n_ref = tiler.create_tiled_segments(img, mask, white_order=1, **kw)
     assert lab.shape == ref.shape
     assert n == n_ref
@@ -107,3 +120,17 @@ def test_sharded_equals_single_process_parity_order(tmp_path, oracle, world, H, 
     assert adjusted_rand_index(lab, ref) == 1.0          # identical partition
     ids = np.unique(lab[lab > 0])
     assert ids[0] == 1 and ids[-1] == n and len(ids) == n
+    stats = np.stack([np.load(tmp_path / f"stats{r}.npy") for r in range(world)])
+    assert stats[:, 2].sum() > 0                         # foreign segments were imported
+    if world == 4:
+        assert stats[:, 0].sum() > 0 and stats[:, 1].sum() > 0, f"kill lists must cross seams in both directions: {stats}"
+
+
+def test_sharded_driver_rejects_small_tiles_and_unknown_kwargs():
+    """tile_size <= 2 * buffer + 1 breaks the seam protocol: refused up front, like unknown SLIC kwargs."""
+    import inspect
+    from obia_amd import distributed
+    src = inspect.getsource(distributed.ShardedTiler.__init__)
+    assert "2 * self.B + 1" in src
+    with pytest.raises((TypeError, NotImplementedError, AssertionError, AttributeError)):
+        distributed.HipTilerEngine(torch.zeros((4, 4, 1)), None, 4, 0, 4, 1, 1.0, (1.0, 1.0), {"bogus": 1}, 0)
