@@ -196,7 +196,8 @@ int obia_texture_stats_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_
  * Arithmetic is float64, the dtype of the pinned scikit-image 0.18.3 kernel.  tie_noise_hw: the (H,W) float64
  * noise scikit-image adds to the densities, RandomState(random_seed).normal(scale=1e-5) -- generated by the host
  * (NumPy's legacy stream is stable); NULL = no noise.  labels_out: consecutive ids from 0 in ascending order of the
- * root pixel (np.unique(...)[1]).  kernel_size <= 5 and 1, 3 or 4 bands in this version.                          */
+ * root pixel (np.unique(...)[1]).  Up to 16 bands, any kernel_size >= 1 (1 / 3 / 4 bands with kernel_size <= 5 -- the
+ * reference's usual calls -- take the LDS-staged kernel, everything else the same arithmetic on global memory).           */
 int obia_quickshift_f32(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
                         double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
                         int32_t *labels_out, int *n_labels_out);

@@ -8,6 +8,9 @@
 // versions also take float32 -- see DESIGN.md).  Not HBM-bound: (2*ceil(3*ks)+1)^2 = 961 neighbour evaluations
 // with one exp() each per pixel at ks = 5; the neighbourhood is staged in LDS as channel planes (lanes read
 // consecutive doubles: conflict-free), a 16x16 pixel tile per workgroup, 46x46x3 doubles = 50.8 KB.
+// Any band count (1..16) and any kernel_size are accepted, as the reference forwards **kwargs untouched: when the
+// neighbourhood of a tile does not fit the LDS (more than 4 bands, or a window wider than the staged one) the same
+// arithmetic runs on the channel planes in global memory (qs_density_parent_global_kernel).
 #include "slic.hpp"
 
 #include <cmath>
@@ -16,7 +19,7 @@ namespace obia {
 
 constexpr int QT = 16;          // tile side
 constexpr int QKW_MAX = 15;     // largest half-window staged in LDS (kernel_size <= 5)
-constexpr int QC = 3;           // channels (Lab) -- other channel counts take the generic path below
+constexpr int QC_MAX = 16;      // bands accepted (the feature pass packs at most 16)
 
 __device__ __forceinline__ void rgb2lab_f64(double r, double g, double b, double &L, double &A, double &B) {
     double a[3] = {r, g, b};
@@ -129,6 +132,52 @@ __global__ __launch_bounds__(QT * QT) void qs_density_parent_kernel(const double
     }
 }
 
+// The same two phases without LDS staging: any band count, any window.  Neighbours are read from the channel planes in
+// global memory (a tile's lanes read 16 consecutive doubles of a row: coalesced, served by L1 / L2 after the first touch).
+__global__ __launch_bounds__(QT * QT) void qs_density_parent_global_kernel(const double *__restrict__ img, const double *__restrict__ noise,
+                                                                          int H, int W, int C, int kw, double inv, int phase,
+                                                                          double *__restrict__ dens, int *__restrict__ parent,
+                                                                          double *__restrict__ dist_parent) {
+    const int ly = threadIdx.x / QT, lx = threadIdx.x % QT;
+    const int r = blockIdx.y * QT + ly, c = blockIdx.x * QT + lx;
+    if (r >= H || c >= W) return;
+    const long long npix = (long long)H * W;
+    const long long me = (long long)r * W + c;
+    double cur[QC_MAX];
+#pragma unroll
+    for (int ch = 0; ch < QC_MAX; ++ch) cur[ch] = ch < C ? img[(long long)ch * npix + me] : 0.0;
+    const int r0 = max(r - kw, 0), r1 = min(r + kw + 1, H), c0 = max(c - kw, 0), c1 = min(c + kw + 1, W);
+    auto dist_to = [&](int r_, int c_) {
+        const long long q = (long long)r_ * W + c_;
+        double dist = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < QC_MAX; ++ch)
+            if (ch < C) { const double t = cur[ch] - img[(long long)ch * npix + q]; dist += t * t; }
+        const double tr = (double)(r - r_), tc = (double)(c - c_);
+        dist += tr * tr;
+        dist += tc * tc;
+        return dist;
+    };
+    if (phase == 1) {
+        double acc = 0.0;
+        for (int r_ = r0; r_ < r1; ++r_)
+            for (int c_ = c0; c_ < c1; ++c_) acc += exp(dist_to(r_, c_) * inv);
+        dens[me] = acc + (noise ? noise[me] : 0.0);
+    } else {
+        const double cd = dens[me];
+        double closest = INFINITY;
+        int par = (int)me;
+        for (int r_ = r0; r_ < r1; ++r_)
+            for (int c_ = c0; c_ < c1; ++c_)
+                if (dens[(long long)r_ * W + c_] > cd) {
+                    const double dist = dist_to(r_, c_);
+                    if (dist < closest) { closest = dist; par = r_ * W + c_; }
+                }
+        parent[me] = par;
+        dist_parent[me] = sqrt(closest);
+    }
+}
+
 // P3: remove links longer than max_dist, then pointer jumping until every pixel points at its root
 __global__ void qs_cut_kernel(int *__restrict__ parent, const double *__restrict__ dist_parent, long long n, double max_dist) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -213,9 +262,12 @@ static int quickshift_dev(obia_ctx *ctx, const float *img, int H, int W, int C, 
     if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels"); return OBIA_E_INVALID; }
     if (!(kernel_size >= 1.0)) { set_error("`kernel_size` should be >= 1."); return OBIA_E_INVALID; }
     if (convert2lab && C != 3) { set_error("Only RGB images can be converted to Lab space."); return OBIA_E_INVALID; }
-    if (C != 1 && C != 3 && C != 4) { set_error("quickshift: %d bands not supported yet (1, 3 or 4)", C); return OBIA_E_UNSUPPORTED; }
+    if (C > QC_MAX) { set_error("quickshift: more than %d bands not supported (got %d)", QC_MAX, C); return OBIA_E_UNSUPPORTED; }
+    if (!(kernel_size < 1.0e4)) { set_error("`kernel_size` too large"); return OBIA_E_INVALID; }
     const int kw = (int)std::ceil(3.0 * kernel_size);
-    if (kw > QKW_MAX) { set_error("quickshift: kernel_size > 5 (window %d) not supported yet", 2 * kw + 1); return OBIA_E_UNSUPPORTED; }
+    // the LDS-staged kernel covers the reference's usual calls (1, 3 or 4 bands, kernel_size <= 5); everything else runs the
+    // same arithmetic on global memory
+    const bool staged = (C == 1 || C == 3 || C == 4) && kw <= QKW_MAX;
     Arena &A = ctx->arena;
     const long long n = (long long)H * W;
     // 1. obia's per-band normalisation (float32, segment_boundaries.py:32-33) through the SLIC feature kernels
@@ -249,7 +301,10 @@ static int quickshift_dev(obia_ctx *ctx, const float *img, int H, int W, int C, 
                        sizeof(double) * (size_t)(CV + (PH == 2 ? 1 : 0)) * side * side, ctx->stream, d_img, noise, H, W, kw, inv, \
                        PH, d_dens, d_par, d_dp); } while (0)
     for (int ph = 1; ph <= 2; ++ph) {
-        if (C == 1) { if (ph == 1) QS_LAUNCH(1, 1); else QS_LAUNCH(1, 2); }
+        if (!staged)
+            hipLaunchKernelGGL(qs_density_parent_global_kernel, grid, dim3(QT * QT), 0, ctx->stream, d_img, noise, H, W, C, kw, inv, ph,
+                               d_dens, d_par, d_dp);
+        else if (C == 1) { if (ph == 1) QS_LAUNCH(1, 1); else QS_LAUNCH(1, 2); }
         else if (C == 3) { if (ph == 1) QS_LAUNCH(3, 1); else QS_LAUNCH(3, 2); }
         else { if (ph == 1) QS_LAUNCH(4, 1); else QS_LAUNCH(4, 2); }
     }
@@ -258,7 +313,7 @@ static int quickshift_dev(obia_ctx *ctx, const float *img, int H, int W, int C, 
     // 4. cut, flatten
     hipLaunchKernelGGL(qs_cut_kernel, dim3(gs), dim3(256), 0, ctx->stream, d_par, d_dp, n, max_dist);
     int *pa = d_par, *pb = d_par2;
-    for (int it = 0; it < 64; ++it) {
+    for (int it = 0; it < 64; ++it) {   // pointer jumping halves every chain: 31 rounds reach the root of any chain below 2^31
         OBIA_HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(qs_jump_kernel, dim3(gs), dim3(256), 0, ctx->stream, pa, pb, n, d_flags);
         std::swap(pa, pb);

