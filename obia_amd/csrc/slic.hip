@@ -612,6 +612,15 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         if (nt > tile_max) tile_max = nt;
     }
     b.total_tiles_all = tiles_all > 0 ? tiles_all : 1;
+    {   // tile -> problem table of the sweep's one-dimensional, XCD-aware grid (slic_sweep.hip)
+        std::vector<int> tp((size_t)b.total_tiles_all, 0);
+        for (int p = 0; p < np; ++p)
+            for (int t = 0; t < b.probs[p].tiles_x * b.probs[p].tiles_y; ++t) tp[(size_t)b.probs[p].tile_off + t] = p;
+        b.d_tile_prob = A.get<int>(tp.size());
+        if (!b.d_tile_prob) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemcpyAsync(b.d_tile_prob, tp.data(), sizeof(int) * tp.size(), hipMemcpyHostToDevice, ctx->stream));
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tp is pageable
+    }
     b.total_cells = cell_off > 0 ? cell_off : 1;
     b.total_tiles = tile_max;
     OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));

@@ -56,6 +56,7 @@ struct SlicBatch {
     int32_t *d_labels = nullptr;       // [total_pix] problem-local labels (start_label based)
     float *d_seed = nullptr;           // [total_cent][2]
     int *d_cent_prob = nullptr;        // [total_cent]
+    int *d_tile_prob = nullptr;        // [total_tiles_all] problem of every sweep tile, tiles numbered problem by problem in raster order
     float *d_cent = nullptr;           // [total_cent][8 + CP] records
     int *d_head = nullptr, *d_next = nullptr;   // d_head: two buffers of total_cells (double-buffered per sweep)
     int *d_head_cur = nullptr;

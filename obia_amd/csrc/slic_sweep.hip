@@ -59,6 +59,9 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #ifndef ASSIGN_WAVES
 #define ASSIGN_WAVES 5
 #endif
+#ifndef OBIA_XCD_GROUP
+#define OBIA_XCD_GROUP 2
+#endif
 constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); must stay <= 128: the slot number
                                 // rides in the low 7 bits of the scoring keys
 
@@ -271,7 +274,7 @@ __device__ __forceinline__ void slic_assign_body(
     int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color_arg,
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
-    unsigned long long *__restrict__ px_counter) {
+    unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all) {
     // colours are folded by every sweep that runs this body without LEAN (the colour sweeps and the last pre-pass sweep)
     // and by none that runs it with LEAN: a compile-time constant either way
     (void)accum_color_arg;
@@ -279,9 +282,19 @@ __device__ __forceinline__ void slic_assign_body(
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
     // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
-    const SlicProblem P = probs[blockIdx.y];
-    const int tile = blockIdx.x;
-    if (tile >= P.tiles_x * P.tiles_y) return;
+    // One-dimensional grid over all tiles of the batch, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blocks b
+    // and b + 8 share one, each XCD has its own L2), so XCD x = blockIdx.x % 8 takes the x-th contiguous EIGHTH of the tiles
+    // (problem by problem, raster order) instead of every eighth tile: neighbouring tiles -- which stage the same centroid
+    // records and touch the same mask lines -- meet in one L2 instead of fetching them from HBM once per XCD.
+#ifndef OBIA_XCD_GROUP
+#define OBIA_XCD_GROUP 2
+#endif
+    constexpr int XG = OBIA_XCD_GROUP;   // consecutive tiles that share an XCD
+    const int gtile = (((int)(blockIdx.x >> 3) / XG) * 8 + (int)(blockIdx.x & 7)) * XG + (int)(blockIdx.x >> 3) % XG;
+    if (gtile >= total_tiles_all) return;
+    const int prob_i = tile_prob[gtile];
+    const SlicProblem P = probs[prob_i];
+    const int tile = gtile - P.tile_off;
     constexpr int RS = CENT_REC + CP;
     constexpr int AQ = LEAN ? 1 : CP + 1;       // qwords of an LDS accumulator: colours (not in the lean kernel), then one packed word
     constexpr int PWI = LEAN ? 0 : CP;          // index of the packed word
@@ -292,8 +305,10 @@ __device__ __forceinline__ void slic_assign_body(
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
     __shared__ unsigned long long s_acc[MAXC][AQ];
-    __shared__ int s_tf[LEAN ? 1 : NT / 64][LEAN ? 1 : CP][LEAN ? 1 : 65];    // 65: row stride that keeps the transposed reads conflict-free
-    __shared__ int s_tkey[LEAN ? 1 : NT / 64][LEAN ? 1 : 64];
+    // transposed scratch of the fold: [wave][layer = first / second run of a lane][field = colours, packed integer word][lane]
+    constexpr int NF = LEAN ? 1 : CP + 1;
+    __shared__ int s_tf[NT / 64][2][NF][65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ int s_tkey[NT / 64][2][64];
     __shared__ unsigned s_orph[SWEEP_TH * SWEEP_TW / 32];   // valid pixels no window reached (rare): handled after the footprints
     __shared__ int s_cnt, s_uncacheable;
 
@@ -312,31 +327,31 @@ __device__ __forceinline__ void slic_assign_body(
     const int yb = fy0 + PPT * (lane >> 4);
     const bool want_feat = !IGNORE_COLOR || accum_color;
     float f[PPT][LEAN ? 1 : CP];
-    bool valid[PPT];
+    unsigned char mb[PPT];    // mask bytes of the lane's four pixels (turned into `valid` at the label stage: nothing waits for them earlier)
     // Addresses: one wave-uniform 64-bit base per footprint (scalar registers) plus a 32-bit lane offset -- a pixel's
     // address costs one or two vector instructions instead of a 64-bit multiply-add chain (16 rows x W x 32 B fits 32
-    // bits: check_slic_args limits W).  The mask bytes and the features of the four pixels are INDEPENDENT loads (all
+    // bits: slic_run_sweeps limits W).  The mask bytes and the features of the four pixels are INDEPENDENT loads (all
     // twelve in flight at once; a masked pixel's features are fetched and never used): a feature load that waits for
     // its mask byte costs a second full memory round trip per pixel.
+    // The loads of footprint b + 1 are issued in iteration b, right after the last use of the feature registers (the
+    // centroid update) -- one call site inside the loop, so the registers are loop-carried without copies, and the
+    // fold, the next scoring and the first selection run under the memory latency.  `real` = false (no next footprint):
+    // every lane reads the first pixel of the current footprint -- one cache line, no branch around the loads.
     const unsigned lrow = (unsigned)(PPT * (lane >> 4)) * (unsigned)P.W + (unsigned)(lane & 15);   // pixel 0 of the strip, relative to (fy0, fx0)
-    auto fetch = [&](int fx0, int yb, unsigned lrow) {   // (the lane's row base and offset come in as opaque per-footprint copies)
+    auto fetch = [&](int fx0, int yb, unsigned lrow, bool real) {   // (row base and offset come in as opaque per-footprint copies)
         const int xx = fx0 + (lane & 15);
         const long long fbase = P.pix_off + (long long)fy0 * P.W + fx0;      // wave-uniform
         const uint8_t *mbase = mask + (MASKED ? fbase : 0);
         const char *fbase_p = reinterpret_cast<const char *>(feat + fbase * (LEAN ? 0 : CP));
-        unsigned char mb[PPT];
-        bool inimg[PPT];
+        unsigned off[PPT];
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            inimg[j] = (yb + j < P.H) && (xx < P.W);
-            const unsigned off = inimg[j] ? lrow + (unsigned)j * (unsigned)P.W : 0u;
-            mb[j] = MASKED ? mbase[off] : (unsigned char)1;
-        }
+        for (int j = 0; j < PPT; ++j) off[j] = (real && (yb + j < P.H) && (xx < P.W)) ? lrow + (unsigned)j * (unsigned)P.W : 0u;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) mb[j] = MASKED ? mbase[off[j]] : (unsigned char)1;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             if (!LEAN && want_feat) {
-                const unsigned off = inimg[j] ? lrow + (unsigned)j * (unsigned)P.W : 0u;
-                const float4 *src = reinterpret_cast<const float4 *>(fbase_p + (size_t)(off * (unsigned)(CP * 4)));
+                const float4 *src = reinterpret_cast<const float4 *>(fbase_p + (size_t)(off[j] * (unsigned)(CP * 4)));
 #pragma unroll
                 for (int q = 0; q < CP / 4; ++q) {
                     const float4 t = src[q];
@@ -347,10 +362,8 @@ __device__ __forceinline__ void slic_assign_body(
                 for (int c = 0; c < (LEAN ? 1 : CP); ++c) f[j][c] = 0.0f;
             }
         }
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) valid[j] = inimg[j] && (mb[j] != 0);
     };
-    if (!FIXPT && wave_active) fetch(tx0, yb, lrow);
+    if (!FIXPT && wave_active) fetch(tx0, yb, lrow, true);
     constexpr int GQ = CP + 3;   // global record / cache entry: colours, n, sum_y, sum_x
     const int tile_id = P.tile_off + tile;
     // bins whose centroids can reach the tile: candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with
@@ -394,7 +407,7 @@ __device__ __forceinline__ void slic_assign_body(
     if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
     __syncthreads();
 
-    if (FIXPT && wave_active) fetch(tx0, yb, lrow);
+    if (FIXPT && wave_active) fetch(tx0, yb, lrow, true);
 
     auto do_stage = [&]() {
     // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
@@ -474,7 +487,6 @@ __device__ __forceinline__ void slic_assign_body(
         const int fx1 = min(fx0 + FB, P.W);
         const int x = fx0 + (lane_i & 15);
         const float fx = (float)x;
-        if (bxi > 0) fetch(fx0, yb_i, lrow_i);
         // pixel state: key = float_bits(best distance) << 32 | slot of the best candidate.  Every pixel starts at
         // (+inf, 0): nothing with d = inf is ever smaller (the reference's `inf > inf` never assigns), and "assigned"
         // is d < inf.  Masked / outside pixels are evaluated like the others (their features are zeros or unused values)
@@ -601,21 +613,24 @@ __device__ __forceinline__ void slic_assign_body(
         int pk[PPT];   // accumulation key: LDS slot, or -1
         int32_t *lbase = labels + (P.pix_off + (long long)fy0 * P.W + fx0);   // wave-uniform
         bool orphan = false;
+        bool valid[PPT];
+        int kslot[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) kslot[j] = __float_as_int(s_hdr[(unsigned)bk[j]][6]);   // four LDS reads in flight (slot 0 while unassigned)
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const bool inimg = (yb_i + j < P.H) && (x < P.W);
+            valid[j] = inimg && (mb[j] != 0);
             const bool assigned = valid[j] && ((unsigned)(bk[j] >> 32) < INF_BITS);
-            const int slot = (int)(unsigned)bk[j];
-            pk[j] = assigned ? slot : -1;
+            pk[j] = assigned ? (int)(unsigned)bk[j] : -1;
             // a valid pixel no window reaches keeps the previous sweep's label (`nearest` is only initialised once,
             // before the loop): nothing is stored, the pixel is noted in the tile's bitmap and accumulated under its old
             // label after the footprints (rare: centroids that drifted away from a thin piece of the mask)
             const bool orph = valid[j] && !assigned;
             orphan |= orph;
-            if (inimg && !orph) {
-                const int lab = assigned ? (__float_as_int(s_hdr[slot][6]) - P.cent_off + start_label) : (start_label - 1);
-                __builtin_nontemporal_store(lab, lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
-            }
+            if (inimg && !orph)
+                __builtin_nontemporal_store(assigned ? kslot[j] - P.cent_off + start_label : start_label - 1,
+                                            lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
         }
         if (__ballot(orphan)) {   // wave-uniform, rare
 #pragma unroll
@@ -627,30 +642,38 @@ __device__ __forceinline__ void slic_assign_body(
                 }
         }
         STAMP(4)   // labels
-        if (!accumulate) continue;
 
         // ---- 3. fused centroid update ------------------------------------------------------------------------------------
-        // Integer part (n, sum_y, sum_x): one packed 64-bit LDS atomic per run, tile-relative coordinates.
-        // Colour part: per-lane runs of equal slot over the strip, summed as 32-bit fixed point; the FIRST run
-        // of every lane goes through the transposed fold below, later runs (a strip crossing a segment boundary) go
-        // straight to the LDS accumulators.
-        if (!LEAN && accum_color) s_tkey[wv][lane_i] = -1;
+        // LDS atomics on one address are executed one lane after the other (~5 cycles each), and a footprint only holds three
+        // or four slots: sixty-four lanes adding to them directly keep the CU's LDS busy longer than all the arithmetic of the
+        // footprint takes (stamped at 1 / 2 / 5 waves per SIMD: profiles/r02_lds_atomics.md).  So NO lane adds its own sums:
+        // the first and the second run of a lane's strip (a strip crossing one segment boundary) are written to a
+        // transposed scratch -- colours as 32-bit fixed point, the integer part packed as
+        // n | sum(y - ty0) << 8 | n * (x - tx0) << 20 -- and a few fold lanes walk them sequentially, adding a partial to
+        // the LDS accumulators only where the slot changes.  A third run of a strip (rare) adds directly.
+        if (accumulate) {
+        s_tkey[wv][0][lane_i] = -1;
+        s_tkey[wv][1][lane_i] = -1;
         {
-            const unsigned long long xrel = (unsigned long long)(x - tx0);
+            const unsigned xrel = (unsigned)(x - tx0);
             int rkey = -1, nruns = 0;
-            unsigned rn = 0, ry = 0;
+            unsigned pw = 0;     // packed integer word of the run
             int rf[LEAN ? 1 : CP];
 #pragma unroll
             for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
             auto close_run = [&]() {
                 if (rkey < 0) return;
-                atomicAdd(&s_acc[rkey][PWI], (unsigned long long)rn | ((unsigned long long)ry << 16) | ((rn * xrel) << 40));
-                if (!LEAN && accum_color) {
-                    if (nruns == 0) {   // the lane's slot in the transposed scratch
-                        s_tkey[wv][lane_i] = rkey;
+                if (nruns < 2) {   // the lane's column in layer `nruns` of the transposed scratch
+                    s_tkey[wv][nruns][lane_i] = rkey;
+                    s_tf[wv][nruns][NF - 1][lane_i] = (int)pw;
+                    if (!LEAN && accum_color) {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) s_tf[wv][LEAN ? 0 : ch][lane_i] = rf[LEAN ? 0 : ch];
-                    } else {
+                        for (int ch = 0; ch < CP; ++ch) s_tf[wv][nruns][LEAN ? 0 : ch][lane_i] = rf[LEAN ? 0 : ch];
+                    }
+                } else {
+                    atomicAdd(&s_acc[rkey][PWI], (unsigned long long)(pw & 0xffu) | ((unsigned long long)((pw >> 8) & 0xfffu) << 16) |
+                                                     ((unsigned long long)(pw >> 20) << 40));
+                    if (!LEAN && accum_color) {
 #pragma unroll
                         for (int ch = 0; ch < CP; ++ch) atomicAdd(&s_acc[rkey][LEAN ? 0 : ch], (unsigned long long)(long long)rf[LEAN ? 0 : ch]);
                     }
@@ -661,12 +684,12 @@ __device__ __forceinline__ void slic_assign_body(
             for (int j = 0; j < PPT; ++j) {
                 if (pk[j] != rkey) {
                     close_run();
-                    rkey = pk[j]; rn = 0; ry = 0;
+                    rkey = pk[j]; pw = 0;
 #pragma unroll
                     for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
                 }
                 if (pk[j] >= 0) {
-                    rn += 1; ry += (unsigned)(yb_i + j - ty0);
+                    pw += 1u | ((unsigned)(yb_i + j - ty0) << 8) | (xrel << 20);
                     if (!LEAN && accum_color) {
 #pragma unroll
                         for (int ch = 0; ch < CP; ++ch) rf[LEAN ? 0 : ch] += to_fixed32(f[j][LEAN ? 0 : ch], fs);
@@ -675,29 +698,63 @@ __device__ __forceinline__ void slic_assign_body(
             }
             close_run();
         }
+        }
         STAMP(5)   // run merge
-        if (LEAN || !accum_color) continue;   // wave-uniform: spatial-only pre-pass sweeps fold no colours
-        // transposed fold: lane (fld, g) folds the 8 strips 8g .. 8g+7 of colour field fld
+        {   // the feature registers are free: request the next footprint (the ONLY call site inside the loop)
+            const bool has_next = (bxi + 1 < SWEEP_TW / FB) && (fx0 + FB < P.W);   // wave-uniform
+            fetch(has_next ? fx0 + FB : fx0, yb_i, lrow_i, has_next);
+        }
+        if (!accumulate) continue;
+        // transposed fold.  Colours: lane (fld, g) walks the strips 8g .. 8g+7 of colour field fld, layer by layer.  The packed
+        // words of both layers are walked by sixteen lanes (layer, g).  The sub-fields of a packed word cannot carry into each
+        // other over 8 strips (n <= 32 < 2^8, coordinate sums <= 8 * 252 < 2^12): it is summed as one integer and unpacked
+        // into the 64-bit format of the LDS accumulators when a partial is added.
         wave_lds_sync();
+        if (!LEAN && accum_color) {
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int fld = 8 * pass + (lane_i & 7), g = lane_i >> 3;
-            if (fld < CP) {
-                int cur = -1;
-                long long sum = 0;
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int fld = 8 * pass + (lane_i & 7), g = lane_i >> 3;
+                if (fld < CP) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int src = 8 * g + i;
-                    const int tk = s_tkey[wv][src];
-                    const int v = tk >= 0 ? s_tf[wv][LEAN ? 0 : fld][src] : 0;   // strips without a run left stale data
-                    if (tk != cur) {
+                    for (int layer = 0; layer < 2; ++layer) {
+                        int cur = -1;
+                        long long sum = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int src = 8 * g + i;
+                            const int tk = s_tkey[wv][layer][src];
+                            const int v = s_tf[wv][layer][LEAN ? 0 : fld][src];   // stale where tk < 0: never added
+                            if (tk != cur) {
+                                if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], (unsigned long long)sum);
+                                cur = tk; sum = 0;
+                            }
+                            sum += (long long)v;
+                        }
                         if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], (unsigned long long)sum);
-                        cur = tk; sum = 0;
                     }
-                    sum += (long long)v;
                 }
-                if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], (unsigned long long)sum);
             }
+        }
+        if (lane_i < 16) {
+            const int layer = lane_i >> 3, g = lane_i & 7;
+            int cur = -1;
+            unsigned sum = 0;
+            auto emit = [&]() {
+                atomicAdd(&s_acc[cur][PWI], (unsigned long long)(sum & 0xffu) | ((unsigned long long)((sum >> 8) & 0xfffu) << 16) |
+                                                ((unsigned long long)(sum >> 20) << 40));
+            };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int src = 8 * g + i;
+                const int tk = s_tkey[wv][layer][src];
+                const unsigned v = (unsigned)s_tf[wv][layer][NF - 1][src];
+                if (tk != cur) {
+                    if (cur >= 0) emit();
+                    cur = tk; sum = 0;
+                }
+                sum += v;
+            }
+            if (cur >= 0) emit();
         }
         wave_lds_sync();   // the scratch is rewritten by the next footprint
         STAMP(6)   // fold
@@ -752,10 +809,10 @@ __device__ __forceinline__ void slic_assign_body(
         int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,      \
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
-        unsigned long long *__restrict__ px_counter
+        unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all
 #define OBIA_ASSIGN_ARGS                                                                                               \
     probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, accum_color, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
@@ -817,19 +874,21 @@ struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; 
 template <int CP>
 static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color,
                           const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
-    dim3 grid(b.total_tiles, b.nprob);
+    constexpr int XGH = OBIA_XCD_GROUP;
+    dim3 grid(8 * XGH * (unsigned)(((int)b.total_tiles_all + 8 * XGH - 1) / (8 * XGH)));   // whole groups of 8 XCDs x XG tiles (see slic_assign_body)
     const int RQ = acc_record_qwords(CP);
 #define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
                        accum_color, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,   \
-                       use_cache, px_counter)
+                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
                        b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, accum_color,           \
-                       b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter)
+                       b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
+                       (int)b.total_tiles_all)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
         if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \

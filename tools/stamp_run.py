@@ -1,4 +1,5 @@
-"""Diagnostic (make -C obia_amd/csrc -B STAMP=1 first): per-phase wave-cycle shares of the sweep kernel."""
+"""Diagnostic (tools/build_variant.sh stampN -DOBIA_STAMP -DASSIGN_WAVES=N, then OBIA_HIP_LIB=...): per-phase wave-cycle shares of
+the sweep kernel on the bench-like masked tiled workload (one 4096^2 raster, tile 2048)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +26,7 @@ tot = sum(out[i] for i in range(8))
 print("waves", out[15], "cycles/wave", tot / max(1, out[15]))
 for i, nme in enumerate(names):
     print(f"  {nme:14s} {out[i]/max(1,out[15]):10.0f} cyc/wave  {100.0*out[i]/tot:5.1f} %")
-cn = ["footprints", "visits", "visits evaluating colours", "visits improving a pixel", "candidate pixels (sum over visits)"]
+cn = ["footprints", "visits", "visits evaluating colours", "j-slices evaluated", "candidate pixels (sum over visits)"]
 fp = max(1, out[8])
 for i, nme in enumerate(cn):
     print(f"  {nme:36s} {out[8+i]:14d}  per footprint {out[8+i]/fp:8.2f}")
