@@ -307,8 +307,15 @@ __device__ __forceinline__ void slic_assign_body(
     __shared__ unsigned long long s_acc[MAXC][AQ];
     // transposed scratch of the fold: [wave][layer = first / second run of a lane][field = colours, packed integer word][lane]
     constexpr int NF = LEAN ? 1 : CP + 1;
-    __shared__ int s_tf[NT / 64][2][NF][65];    // 65: row stride that keeps the transposed reads conflict-free
-    __shared__ int s_tkey[NT / 64][2][64];
+#ifndef OBIA_FOLD_LAYERS
+#define OBIA_FOLD_LAYERS 1
+#endif
+    // runs of a lane's strip that go through the fold: the spatial-only pre-pass kernel is bound by its arithmetic, not by the
+    // LDS -- its one packed word per run is added directly
+    constexpr int FOLD_LAYERS = LEAN ? 0 : OBIA_FOLD_LAYERS;
+    constexpr int FLD = FOLD_LAYERS > 0 ? FOLD_LAYERS : 1;
+    __shared__ int s_tf[LEAN ? 1 : NT / 64][FLD][NF][LEAN ? 1 : 65];    // 65: row stride that keeps the transposed reads conflict-free
+    __shared__ int s_tkey[LEAN ? 1 : NT / 64][FLD][LEAN ? 1 : 64];
     __shared__ unsigned s_orph[SWEEP_TH * SWEEP_TW / 32];   // valid pixels no window reached (rare): handled after the footprints
     __shared__ int s_cnt, s_uncacheable;
 
@@ -644,16 +651,15 @@ __device__ __forceinline__ void slic_assign_body(
         STAMP(4)   // labels
 
         // ---- 3. fused centroid update ------------------------------------------------------------------------------------
-        // LDS atomics on one address are executed one lane after the other (~5 cycles each), and a footprint only holds three
-        // or four slots: sixty-four lanes adding to them directly keep the CU's LDS busy longer than all the arithmetic of the
-        // footprint takes (stamped at 1 / 2 / 5 waves per SIMD: profiles/r02_lds_atomics.md).  So NO lane adds its own sums:
-        // the first and the second run of a lane's strip (a strip crossing one segment boundary) are written to a
-        // transposed scratch -- colours as 32-bit fixed point, the integer part packed as
-        // n | sum(y - ty0) << 8 | n * (x - tx0) << 20 -- and a few fold lanes walk them sequentially, adding a partial to
-        // the LDS accumulators only where the slot changes.  A third run of a strip (rare) adds directly.
+        // LDS atomics on one address are executed one lane after the other, and a footprint only holds three or four slots:
+        // sixty-four lanes adding their sums directly cost 11 % of the sweep (measured: OBIA_FOLD_LAYERS = 0 vs 1).  So the
+        // FIRST run of a lane's strip -- three strips out of four hold one run only -- is written to a transposed scratch,
+        // colours as 32-bit fixed point, the integer part packed as  n | sum(y - ty0) << 8 | n * (x - tx0) << 20,  and a few
+        // fold lanes walk it sequentially, adding a partial to the LDS accumulators only where the slot changes.  Later runs
+        // (a strip crossing a segment boundary) add directly: a second scratch layer for them was measured 1 % slower.
         if (accumulate) {
-        s_tkey[wv][0][lane_i] = -1;
-        s_tkey[wv][1][lane_i] = -1;
+        if (FOLD_LAYERS > 0) s_tkey[wv][0][lane_i] = -1;
+        if (FOLD_LAYERS > 1) s_tkey[wv][1][lane_i] = -1;
         {
             const unsigned xrel = (unsigned)(x - tx0);
             int rkey = -1, nruns = 0;
@@ -663,7 +669,7 @@ __device__ __forceinline__ void slic_assign_body(
             for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
             auto close_run = [&]() {
                 if (rkey < 0) return;
-                if (nruns < 2) {   // the lane's column in layer `nruns` of the transposed scratch
+                if (nruns < FOLD_LAYERS) {   // the lane's column in layer `nruns` of the transposed scratch
                     s_tkey[wv][nruns][lane_i] = rkey;
                     s_tf[wv][nruns][NF - 1][lane_i] = (int)pw;
                     if (!LEAN && accum_color) {
@@ -704,7 +710,7 @@ __device__ __forceinline__ void slic_assign_body(
             const bool has_next = (bxi + 1 < SWEEP_TW / FB) && (fx0 + FB < P.W);   // wave-uniform
             fetch(has_next ? fx0 + FB : fx0, yb_i, lrow_i, has_next);
         }
-        if (!accumulate) continue;
+        if (!accumulate || FOLD_LAYERS == 0) continue;
         // transposed fold.  Colours: lane (fld, g) walks the strips 8g .. 8g+7 of colour field fld, layer by layer.  The packed
         // words of both layers are walked by sixteen lanes (layer, g).  The sub-fields of a packed word cannot carry into each
         // other over 8 strips (n <= 32 < 2^8, coordinate sums <= 8 * 252 < 2^12): it is summed as one integer and unpacked
@@ -716,7 +722,7 @@ __device__ __forceinline__ void slic_assign_body(
                 const int fld = 8 * pass + (lane_i & 7), g = lane_i >> 3;
                 if (fld < CP) {
 #pragma unroll
-                    for (int layer = 0; layer < 2; ++layer) {
+                    for (int layer = 0; layer < FOLD_LAYERS; ++layer) {
                         int cur = -1;
                         long long sum = 0;
 #pragma unroll
@@ -735,7 +741,7 @@ __device__ __forceinline__ void slic_assign_body(
                 }
             }
         }
-        if (lane_i < 16) {
+        if (lane_i < 8 * FOLD_LAYERS) {
             const int layer = lane_i >> 3, g = lane_i & 7;
             int cur = -1;
             unsigned sum = 0;
