@@ -213,7 +213,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                           const uint8_t *__restrict__ mask, const float *__restrict__ cent,
                           const int *__restrict__ head, const int *__restrict__ next, int32_t *__restrict__ labels,
                           unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color, int start_label,
-                          float fs) {
+                          float fs, int store_labels, int *__restrict__ orphan_flag) {
     constexpr int RS = CENT_REC + CP;
     const float w = P.spatial_w;
     for (int i = threadIdx.x; i < SWEEP_TW * SWEEP_TH; i += NT) {
@@ -249,6 +249,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                 }
         int k = bk;
         if (k < 0) {   // `nearest` keeps the previous sweep's value
+            if (!store_labels) *orphan_flag = 1;   // ... which was not stored: the host repeats the batch with every sweep storing
             const int prev = labels[pix];
             if (prev >= start_label) k = prev - start_label + P.cent_off;
         } else {
@@ -271,13 +272,13 @@ template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, boo
 __device__ __forceinline__ void slic_assign_body(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
-    int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color_arg,
+    int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int store_labels,
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
-    unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all) {
+    unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
+    int *__restrict__ orphan_flag) {
     // colours are folded by every sweep that runs this body without LEAN (the colour sweeps and the last pre-pass sweep)
     // and by none that runs it with LEAN: a compile-time constant either way
-    (void)accum_color_arg;
     constexpr int accum_color = LEAN ? 0 : 1;
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
@@ -445,7 +446,7 @@ __device__ __forceinline__ void slic_assign_body(
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
         slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
-                                                      accum_color, start_label, fs);
+                                                      accum_color, start_label, fs, store_labels, orphan_flag);
         return;
     }
     auto do_sort = [&]() {
@@ -620,10 +621,16 @@ __device__ __forceinline__ void slic_assign_body(
         int pk[PPT];   // accumulation key: LDS slot, or -1
         int32_t *lbase = labels + (P.pix_off + (long long)fy0 * P.W + fx0);   // wave-uniform
         bool orphan = false;
+        // Only the labels of the LAST sweep are an output.  The labels of the other sweeps are read by nothing but the rare
+        // "orphan" pixels below, so those sweeps do not store them (store_labels = 0: 4 of the 36 bytes per pixel, four
+        // stores and four LDS reads per lane) -- an orphan then raises a flag and the host repeats the batch with every
+        // sweep storing (slic_run_sweeps): the result is the same either way.
         bool valid[PPT];
         int kslot[PPT];
+        if (store_labels) {   // kernel argument: wave-uniform
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) kslot[j] = __float_as_int(s_hdr[(unsigned)bk[j]][6]);   // four LDS reads in flight (slot 0 while unassigned)
+            for (int j = 0; j < PPT; ++j) kslot[j] = __float_as_int(s_hdr[(unsigned)bk[j]][6]);   // four LDS reads in flight (slot 0 while unassigned)
+        }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const bool inimg = (yb_i + j < P.H) && (x < P.W);
@@ -635,11 +642,12 @@ __device__ __forceinline__ void slic_assign_body(
             // label after the footprints (rare: centroids that drifted away from a thin piece of the mask)
             const bool orph = valid[j] && !assigned;
             orphan |= orph;
-            if (inimg && !orph)
+            if (store_labels && inimg && !orph)
                 __builtin_nontemporal_store(assigned ? kslot[j] - P.cent_off + start_label : start_label - 1,
                                             lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
         }
         if (__ballot(orphan)) {   // wave-uniform, rare
+            if (!store_labels && lane_i == 0) *orphan_flag = 1;   // the labels this pixel would keep were not stored: repeat the batch
 #pragma unroll
             for (int j = 0; j < PPT; ++j)
                 if (valid[j] && ((unsigned)(bk[j] >> 32) >= INF_BITS)) {
@@ -768,7 +776,7 @@ __device__ __forceinline__ void slic_assign_body(
 #undef BK_D
     if (!accumulate) { STAMP_FLUSH return; }
     __syncthreads();
-    if (s_uncacheable) {   // workgroup-uniform, rare: the orphan pixels of the tile go straight to the global records
+    if (s_uncacheable && store_labels) {   // workgroup-uniform, rare: the orphan pixels of the tile go straight to the global records
         for (int i = tid; i < SWEEP_TH * SWEEP_TW; i += NT) {
             if (!((s_orph[i >> 5] >> (i & 31)) & 1u)) continue;
             const int y = ty0 + i / SWEEP_TW, x = tx0 + i % SWEEP_TW;
@@ -812,13 +820,14 @@ __device__ __forceinline__ void slic_assign_body(
 #define OBIA_ASSIGN_PARAMS                                                                                             \
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,             \
         const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,                      \
-        int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color,      \
+        int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int store_labels,     \
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
-        unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all
+        unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
+        int *__restrict__ orphan_flag
 #define OBIA_ASSIGN_ARGS                                                                                               \
-    probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, accum_color, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all
+    probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
@@ -878,23 +887,23 @@ struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; 
 };
 
 template <int CP>
-static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color,
-                          const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
+static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color, int store_labels,
+                          int *orphan_flag, const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
     constexpr int XGH = OBIA_XCD_GROUP;
     dim3 grid(8 * XGH * (unsigned)(((int)b.total_tiles_all + 8 * XGH - 1) / (8 * XGH)));   // whole groups of 8 XCDs x XG tiles (see slic_assign_body)
     const int RQ = acc_record_qwords(CP);
 #define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
-                       accum_color, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,   \
-                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all)
+                       store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
+                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
-                       b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, accum_color,           \
+                       b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
                        b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
-                       (int)b.total_tiles_all)
+                       (int)b.total_tiles_all, orphan_flag)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
         if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \
@@ -914,14 +923,14 @@ __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
 }
 
 int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
-    // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
-    {
+    auto fill_labels = [&]() {   // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
         long long n = b.total_pix;
         int blocks = cdiv(n, 256 * 8);
         if (blocks > 65535) blocks = 65535;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
-    }
+    };
+    fill_labels();
     if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
     // the sweep addresses a footprint's pixels as a 64-bit wave-uniform base plus a 32-bit lane offset (16 rows x W x 64 B)
     for (auto &P : b.probs)
@@ -929,10 +938,11 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     const int passes = b.masked ? 2 : 1;   // maskSLIC: spatial-only pre-pass first (slic_superpixels.py:310-314)
     const int RQ = acc_record_qwords(b.CP);
     Arena &A = ctx->arena;
-    // pixel counters (profiling): 256 slots each for the colour sweeps and the pre-pass sweeps, summed on the host
-    unsigned long long *d_px = ctx->profiling ? A.get<unsigned long long>(512) : nullptr;
-    if (ctx->profiling && !d_px) return OBIA_E_NOMEM;
-    if (d_px) OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 512, ctx->stream));
+    // pixel counters (profiling): 256 slots each for the colour sweeps and the pre-pass sweeps, summed on the host;
+    // slot 512: the orphan flag of the sweeps that do not store their labels
+    unsigned long long *d_px = A.get<unsigned long long>(513);
+    if (!d_px) return OBIA_E_NOMEM;
+    int *d_orphan = reinterpret_cast<int *>(d_px + 512);
     FixedPointState fp;
     if (b.exit_on_fixed_point) {
         const size_t nt = (size_t)b.total_tiles_all;
@@ -944,33 +954,40 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         OBIA_HIP_TRY(hipMemsetAsync(fp.bin_stamp, 0, sizeof(int) * (size_t)b.total_cells, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(fp.tile_lp, 0, sizeof(int) * nt, ctx->stream));
     }
-    bool first = true;
-    int sweep_no = 0;
     int maxh_z = 1;
     for (auto &P : b.probs) if (P.H > maxh_z) maxh_z = P.H;
     if (maxh_z > 4096) maxh_z = 4096;
-    OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
-    for (int pass = 0; pass < passes; ++pass) {
-        const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
-        const bool last_pass = (pass == passes - 1);
-        for (int it = 0; it < b.max_iter; ++it) {
-            int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
-            int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
-            ++sweep_no;   // sweep ids start at 1
-            // SLIC-zero: the per-cluster colour scale restarts at 1 with the colour pass and is carried afterwards
-            const int zmode = (b.slic_zero && !ignore_color) ? (it == 0 ? 2 : 1) : 0;
-            if (RQ == 16)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv((long long)b.total_cent * 16, 256)), dim3(256), 0,
-                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                   1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv((long long)b.total_cent * 32, 256)), dim3(256), 0,
-                                   ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                   1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
-            b.d_head_cur = head_cur;
-            first = false;
-            if (zmode == 1) {   // the centroids just moved: raise max_dist_color from the assignment of the last sweep
-                dim3 zg(maxh_z, b.nprob);
+
+    // All sweeps of the batch.  store_all = false: only the very last sweep stores its labels (the others' labels are dead
+    // stores unless a valid pixel is reached by no window -- see the label stage of the sweep); true: every sweep stores, the
+    // reference's literal behaviour, needed by the fixed-point replay (labels "already in place") and by SLIC-zero (its
+    // max-colour-distance pass reads the last assignment).
+    auto run_all = [&](bool store_all) -> int {
+        OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 513, ctx->stream));
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
+        bool first = true;
+        int sweep_no = 0;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
+            const bool last_pass = (pass == passes - 1);
+            for (int it = 0; it < b.max_iter; ++it) {
+                int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
+                int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
+                ++sweep_no;   // sweep ids start at 1
+                // SLIC-zero: the per-cluster colour scale restarts at 1 with the colour pass and is carried afterwards
+                const int zmode = (b.slic_zero && !ignore_color) ? (it == 0 ? 2 : 1) : 0;
+                if (RQ == 16)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv((long long)b.total_cent * 16, 256)), dim3(256), 0,
+                                       ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
+                                       1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv((long long)b.total_cent * 32, 256)), dim3(256), 0,
+                                       ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
+                                       1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+                b.d_head_cur = head_cur;
+                first = false;
+                if (zmode == 1) {   // the centroids just moved: raise max_dist_color from the assignment of the last sweep
+                    dim3 zg(maxh_z, b.nprob);
 #define LAUNCH_MAXDIST(CPV)                                                                                           \
     do {                                                                                                              \
         if (b.masked) hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_maxdist_kernel<CPV, true>), zg, dim3(256), 0, ctx->stream, b.d_probs, \
@@ -978,39 +995,52 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_maxdist_kernel<CPV, false>), zg, dim3(256), 0, ctx->stream, b.d_probs, \
                                 b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label);                            \
     } while (0)
-                switch (b.CP) {
-                    case 4: LAUNCH_MAXDIST(4); break;
-                    case 8: LAUNCH_MAXDIST(8); break;
-                    case 12: LAUNCH_MAXDIST(12); break;
-                    default: LAUNCH_MAXDIST(16); break;
-                }
+                    switch (b.CP) {
+                        case 4: LAUNCH_MAXDIST(4); break;
+                        case 8: LAUNCH_MAXDIST(8); break;
+                        case 12: LAUNCH_MAXDIST(12); break;
+                        default: LAUNCH_MAXDIST(16); break;
+                    }
 #undef LAUNCH_MAXDIST
-            }
-            // the update after the very last sweep is never read: skip its accumulation
-            const int accumulate = (last_pass && it == b.max_iter - 1) ? 0 : 1;
-            const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
-            // the last pre-pass sweep is the only one of its pass that folds colours (they seed the main pass): the
-            // caches written by the earlier pre-pass sweeps hold no colour sums, so it evaluates every tile
-            const int use_cache = (ignore_color && it == b.max_iter - 1) ? 0 : 1;
-            {
-                ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
-                unsigned long long *pxc = d_px ? d_px + (ignore_color ? 256 : 0) : nullptr;
-                switch (b.CP) {
-                    case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
-                    case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
-                    case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
-                    case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, fp, sweep_no, use_cache, pxc); break;
-                    default: set_error("bad CP"); return OBIA_E_INVALID;
+                }
+                // the update after the very last sweep is never read: skip its accumulation
+                const bool very_last = last_pass && it == b.max_iter - 1;
+                const int accumulate = very_last ? 0 : 1;
+                const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
+                const int store_labels = (store_all || very_last) ? 1 : 0;
+                // the last pre-pass sweep is the only one of its pass that folds colours (they seed the main pass): the
+                // caches written by the earlier pre-pass sweeps hold no colour sums, so it evaluates every tile
+                const int use_cache = (ignore_color && it == b.max_iter - 1) ? 0 : 1;
+                {
+                    ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
+                    unsigned long long *pxc = ctx->profiling ? d_px + (ignore_color ? 256 : 0) : nullptr;
+                    switch (b.CP) {
+                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
+                        case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
+                        case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
+                        case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
+                        default: set_error("bad CP"); return OBIA_E_INVALID;
+                    }
                 }
             }
         }
-    }
-    OBIA_HIP_TRY(hipGetLastError());
-    if (d_px) {
-        unsigned long long h[512];
+        OBIA_HIP_TRY(hipGetLastError());
+        return OBIA_OK;
+    };
+    static const bool env_store_all = std::getenv("OBIA_STORE_ALL_LABELS") != nullptr;   // developer switch (A/B timing)
+    const bool store_all = b.exit_on_fixed_point || b.slic_zero || env_store_all;
+    OBIA_TRY(run_all(store_all));
+    unsigned long long h[513];
+    OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
+    if (!store_all && (h[512] & 0xffffffffull) != 0ull) {
+        // a pixel needed the label of an earlier sweep: repeat the batch from the seeds with every sweep storing its labels
+        fill_labels();
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * (size_t)b.total_cent * RQ, ctx->stream));
+        OBIA_TRY(run_all(true));
         OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
-        for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
     }
+    if (ctx->profiling)
+        for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
     return OBIA_OK;
 }
 
