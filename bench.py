@@ -269,13 +269,14 @@ def main():
         step()
     barrier()
     t0 = time.time()
-    assign_ms = assign_px = sweeps = 0.0
+    assign_ms = assign_px = assign_store_px = sweeps = 0.0
     parts = {"features_ms": 0.0, "prepass_ms": 0.0, "assign_ms": 0.0, "connectivity_ms": 0.0, "zonal_ms": 0.0}
     n_seg = 0
     for _ in range(args.steps):
         lab, n_seg, st, t_seg, t_z = step()
         assign_ms += t_seg["assign_ms"]
         assign_px += t_seg["assign_px"]
+        assign_store_px += t_seg["assign_store_px"]
         sweeps += t_seg["sweeps"]
         for k in ("features_ms", "prepass_ms", "assign_ms", "connectivity_ms"):
             parts[k] += t_seg[k]
@@ -296,15 +297,15 @@ def main():
         create_tiled_segments(img, input_mask=mask, **kw2)
         torch.cuda.synchronize()
         t1 = time.time()
-        a_ms = a_px = sw = 0.0
+        a_ms = a_px = a_spx = sw = 0.0
         for _ in range(args.steps):
             lab_c, n_c = create_tiled_segments(img, input_mask=mask, **kw2)
             tt = ctx.timing()
-            a_ms += tt["assign_ms"]; a_px += tt["assign_px"]; sw += tt["sweeps"]
+            a_ms += tt["assign_ms"]; a_px += tt["assign_px"]; a_spx += tt["assign_store_px"]; sw += tt["sweeps"]
             zonal_stats(img, lab_c, n_labels=n_c, ctx=ctx)
         torch.cuda.synchronize()
         d = (time.time() - t1) / args.steps
-        ach = (a_px * (4 * C + 4)) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+        ach = (a_px * 4 * C + a_spx * 4) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
         return {"compactness": c, "value": round(float(H) * W / d / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(d * 1e3, 3),
                 "segments": int(n_c), "sweep_avg_launch_ms": round(a_ms / max(1.0, sw), 4),
                 "sweep_roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
@@ -336,9 +337,14 @@ def main():
     value = total_px / (dt / args.steps) / 1e6
 
     if rank == 0:
+        # algorithmic bytes of a colour sweep: 4C (features read) per pixel, + 4 (label written) on the sweeps that store their
+        # labels -- only the last sweep of a batch does, the other sweeps' labels are dead stores the kernel does not make
+        # (DESIGN.md 3.2).  SURVEY 8d's figure, 4C + 4 on every sweep, is kept beside it for comparison with round 1.
         bytes_per_px = 4 * C + 4
         avg_launch_ms = assign_ms / max(1.0, sweeps)
-        achieved = (assign_px * bytes_per_px) / (assign_ms * 1e-3) / 1e9 if assign_ms > 0 else 0.0
+        alg_bytes = assign_px * 4 * C + assign_store_px * 4
+        achieved = alg_bytes / (assign_ms * 1e-3) / 1e9 if assign_ms > 0 else 0.0
+        achieved_survey = (assign_px * bytes_per_px) / (assign_ms * 1e-3) / 1e9 if assign_ms > 0 else 0.0
         out = {
             "metric": "Mpixel/s (SLIC+zonal feats) on 16384²×8-band; achieved HBM GB/s fraction",
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,7 +361,9 @@ def main():
                          # gfx950 correction; tools/traffic_json.py).  Dated, not live: only reported when the kernel sources
                          # are byte-identical to the ones the counters were collected on and the workload is the same.
                          **traffic_fields(args, C, world),
-                         "bytes_per_pixel": bytes_per_px, "launches": int(sweeps), "avg_launch_ms": round(avg_launch_ms, 4),
+                         "bytes_per_pixel": round(alg_bytes / max(1.0, assign_px), 2), "launches": int(sweeps), "avg_launch_ms": round(avg_launch_ms, 4),
+                         "bytes_note": "4C per pixel read + 4 per pixel written by the sweeps that store labels (1 in 10)",
+                         "frac_at_survey_36B_per_px": round(achieved_survey / HBM_PEAK_GBS, 4),
                          "pixels_per_launch_avg": round(assign_px / max(1.0, sweeps), 1)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in parts.items()},
         }

@@ -264,7 +264,8 @@ int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
  * stream (bench.py's roofline leg).  `what`: 0 = SLIC colour sweeps (sum of launches, ms), 1 = number of
  * those launches, 2 = feature preparation, 3 = connectivity, 4 = zonal statistics, 5 = whole call,
  * 6 = maskSLIC spatial-only pre-pass sweeps (ms), 7 = pixels actually processed by the launches of 0
- * (sum; tiles skipped by exit_on_fixed_point are not counted), 8 = the same for the pre-pass launches.    */
+ * (sum; tiles skipped by exit_on_fixed_point are not counted), 8 = the same for the pre-pass launches,
+ * 9 = pixels of the launches of 0 that also stored their labels (only the last sweep of a batch does).   */
 int obia_set_profiling(obia_ctx *ctx, int enabled);
 double obia_last_timing(obia_ctx *ctx, int what);
 

@@ -55,6 +55,7 @@ class Arena {
 struct Timing {
     double assign_ms = 0, prepass_ms = 0, feat_ms = 0, cc_ms = 0, zonal_ms = 0, total_ms = 0;
     double assign_px = 0, prepass_px = 0;   // pixels processed by the timed colour / pre-pass sweeps (sum over launches)
+    double assign_store_px = 0;             // ... of the colour sweeps that also stored their labels (the last sweep of a batch)
     int sweeps = 0;
 };
 

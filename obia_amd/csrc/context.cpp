@@ -246,6 +246,7 @@ double obia_last_timing(obia_ctx *ctx, int what) {
         case 6: return ctx->timing.prepass_ms;
         case 7: return ctx->timing.assign_px;
         case 8: return ctx->timing.prepass_px;
+        case 9: return ctx->timing.assign_store_px;
         default: return -1.0;
     }
 }

@@ -1014,6 +1014,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 {
                     ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
                     unsigned long long *pxc = ctx->profiling ? d_px + (ignore_color ? 256 : 0) : nullptr;
+                    if (ctx->profiling && !ignore_color && store_labels) ctx->timing.assign_store_px += (double)b.total_pix;
                     switch (b.CP) {
                         case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
                         case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
