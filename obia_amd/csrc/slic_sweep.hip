@@ -57,7 +57,7 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #define LEAN_WAVES 8
 #endif
 #ifndef ASSIGN_WAVES
-#define ASSIGN_WAVES 5
+#define ASSIGN_WAVES 6
 #endif
 #ifndef OBIA_XCD_GROUP
 #define OBIA_XCD_GROUP 2
