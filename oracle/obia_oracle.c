@@ -262,6 +262,10 @@ int obia_oracle_slic_core(const float *image, const uint8_t *mask, float *segmen
             for (int64_t x = 0; x < W; ++x) {
                 if (mask && !mask[y * W + x]) continue;
                 const int64_t k = nearest[y * W + x] - start_label;
+                /* A valid pixel that no window has reached yet still holds mask_label: the Cython code indexes
+                 * n_elems[-1] there (boundscheck off: undefined behaviour).  Defined here, and in the HIP path, as
+                 * "not accumulated". */
+                if (k < 0) continue;
                 n_elems[k] += 1;
                 segments[k * F + 0] += (float)y;
                 segments[k * F + 1] += (float)x;
@@ -275,6 +279,7 @@ int obia_oracle_slic_core(const float *image, const uint8_t *mask, float *segmen
                 for (int64_t x = 0; x < W; ++x) {
                     if (mask && !mask[y * W + x]) continue;
                     const int64_t k = nearest[y * W + x] - start_label;
+                    if (k < 0) continue;   /* as above */
                     float dc = 0.0f;
                     const float *px = image + (y * W + x) * C;
                     for (int c = 0; c < C; ++c) {

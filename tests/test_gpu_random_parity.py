@@ -1,0 +1,68 @@
+"""Randomised parity of the HIP SLIC path against the pinned oracle: shapes that are not multiples of the 64-pixel tile or the
+16-pixel footprint, 1..16 bands, dense and sparse seeds, compactness from colour-dominated to grid-like, masks with holes and
+thin pieces (valid pixels that no window reaches keep their previous label: the sweeps then repeat with every sweep storing
+labels), start_label 0 / 1, few sweeps.  Seeds are fixed: the cases are the same on every run.
+Bar: labels before connectivity differ on <= 1e-4 of the pixels (the only source is the rounding of centroid colour means: exact
+fixed point here, sequential float32 in the reference), final labels ARI >= 0.99; the cases at compactness >= 5 must be bit-exact."""
+import numpy as np
+import pytest
+
+from tests.metrics import adjusted_rand_index, label_disagreement
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make_case(seed):
+    rs = np.random.RandomState(1000 + seed)
+    H = int(rs.choice([7, 33, 64, 65, 100, 129, 190, 257]))
+    W = int(rs.choice([9, 31, 64, 80, 127, 130, 200, 321]))
+    C = int(rs.choice([1, 2, 4, 5, 8, 9, 12, 16]))
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.stack([300 * np.sin(xx / (5 + 2 * c)) * np.cos(yy / (6 + c)) + 800 + 40 * c + rs.normal(0, 25, (H, W))
+                    for c in range(C)], -1).astype(np.float32)
+    n_seg = int(max(2, H * W / rs.choice([9, 30, 80, 200, 500])))
+    comp = float(rs.choice([0.05, 0.25, 1.0, 5.0, 20.0]))
+    mask = None
+    kind = rs.randint(0, 4)
+    if kind == 1:      # disc with a hole
+        mask = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (0.45 * max(H, W)) ** 2) & ~((abs(yy - H / 3) < H / 10) & (abs(xx - W / 2) < W / 8))
+    elif kind == 2:    # thin diagonal stripes: centroids drift, pixels get orphaned
+        mask = ((xx + 2 * yy).astype(np.int64) % 17) < 5
+    elif kind == 3:    # a few scattered rectangles
+        mask = np.zeros((H, W), bool)
+        for _ in range(4):
+            y0, x0 = rs.randint(0, max(1, H - 4)), rs.randint(0, max(1, W - 4))
+            mask[y0:y0 + rs.randint(3, max(4, H // 2)), x0:x0 + rs.randint(3, max(4, W // 2))] = True
+    if mask is not None and mask.sum() < 4:
+        mask = None
+    kw = dict(n_segments=n_seg, compactness=comp, max_num_iter=int(rs.choice([1, 3, 10])), start_label=int(rs.choice([0, 1])),
+              convert2lab=False)
+    return img, mask, kw
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_case_vs_oracle(oracle, seed):
+    from obia_amd.segmentation import slic
+    img, mask, kw = make_case(seed)
+    okw = dict(n_segments=kw["n_segments"], compactness=kw["compactness"], max_iter=kw["max_num_iter"], start_label=kw["start_label"],
+               convert2lab=False, mask=None if mask is None else mask.astype(np.uint8))
+    try:
+        ref, ref_pre, _ = oracle.slic(oracle.normalize(img), return_all=True, **okw)
+    except ValueError:
+        with pytest.raises(ValueError):
+            slic(img, mask=mask, _normalize_bands=True, **kw)
+        return
+    dev = torch.as_tensor(img).cuda()
+    pre = slic(dev, mask=mask, _normalize_bands=True, _stage="pre", **kw).cpu().numpy()
+    lab = slic(dev, mask=mask, _normalize_bands=True, **kw).cpu().numpy()
+    valid = np.ones(img.shape[:2], bool) if mask is None else mask
+    assert ((pre[~valid] == kw["start_label"] - 1).all()) and ((lab[~valid] == kw["start_label"] - 1).all())
+    dis = label_disagreement(pre[valid], ref_pre[valid])
+    assert dis <= 1e-4 or (pre[valid] != ref_pre[valid]).sum() <= 2, f"seed {seed}: {dis:.2e} of pixels differ before connectivity ({img.shape}, {kw})"
+    if kw["compactness"] >= 5.0:
+        assert np.array_equal(pre, ref_pre) and np.array_equal(lab, ref), f"seed {seed}: not bit-exact ({img.shape}, {kw})"
+    else:
+        assert adjusted_rand_index(lab[valid], ref[valid]) >= 0.99
+    # a second run is bit-identical (integer accumulators)
+    assert np.array_equal(slic(dev, mask=mask, _normalize_bands=True, **kw).cpu().numpy(), lab)
