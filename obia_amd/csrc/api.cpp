@@ -41,11 +41,12 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.slic_zero = p->slic_zero != 0;
     b.total_pix = (long long)H * W;
     SlicProblem P{};
-    P.H = H; P.W = W; P.pix_off = 0;
+    P.H = H; P.W = W; P.pix_off = 0; P.feat_off = 0; P.XB = feat_xb(W);
     b.probs.assign(1, P);
-    b.windows.assign(1, SrcWindow{0, 0, H, W, 0});
+    b.windows.assign(1, SrcWindow{0, 0, H, W, 0, 0});
     b.d_windows = A.get<SrcWindow>(1);
-    b.d_feat = A.get<float>((size_t)b.total_pix * b.CP);
+    b.total_feat_f4 = feat_block_f4(H, W, b.CP);
+    b.d_feat = A.get<float>(4 * (size_t)b.total_feat_f4);
     b.d_labels = A.get<int32_t>((size_t)b.total_pix);
     if (!b.d_windows || !b.d_feat || !b.d_labels) return OBIA_E_NOMEM;
     OBIA_HIP_TRY(hipMemcpyAsync(b.d_windows, b.windows.data(), sizeof(SrcWindow), hipMemcpyHostToDevice, ctx->stream));

@@ -182,20 +182,48 @@ __device__ __forceinline__ void rgb2lab_f32(float r, float g, float b, float &L,
     B = 200.0f * (xyz[1] - xyz[2]);
 }
 
-// K0b: features = [normalize_band] -> [rgb2lab] -> * float32(1/compactness), written to the dense
-// per-problem buffer padded to CP channels (padding is 0: `t = 0 - 0; dc += t*t` leaves every
-// distance bit-identical).  Also reduces max|feature| for the fixed-point scale.  Per-band min and
-// (max - min) are hoisted into registers; C % 4 == 0 rasters are read as float4.
+// one pixel: [normalize_band] -> [rgb2lab] -> * ratio; returns max |feature|
 template <int CP>
-__global__ __launch_bounds__(256) void features_kernel(const float *__restrict__ src, int Ws, int C,
-                                                       const SrcWindow *__restrict__ wins,
-                                                       const unsigned *__restrict__ keys, int normalize,
-                                                       int to_lab, float ratio, float *__restrict__ feat,
-                                                       unsigned *__restrict__ maxabs_bits) {
-    const int p = blockIdx.y;
-    const SrcWindow wdw = wins[p];
-    const long long npix = (long long)wdw.h * wdw.w;
-    float bmn[CP], bden[CP];
+__device__ __forceinline__ float feature_pixel(const float *__restrict__ px, int C, bool vec, int normalize, int to_lab, float ratio,
+                                               const float (&bmn)[CP], const float (&bden)[CP], float (&v)[CP]) {
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < CP / 4; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(px)[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) v[c] = (c < C) ? px[c] : 0.0f;
+    }
+    if (normalize) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            float t = (v[c] - bmn[c]) / bden[c];
+            if (!(fabsf(t) <= 3.0e38f)) t = 0.0f;   // constant / non-finite band: the problem is rejected on the host
+            v[c] = t;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) if (!(fabsf(v[c]) <= 3.0e38f)) v[c] = 0.0f;
+    }
+    if (to_lab) {
+        float L, A, B;
+        rgb2lab_f32(v[0], v[1], v[2], L, A, B);
+        v[0] = L; v[1] = A; v[2] = B;
+    }
+    float m = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        v[c] = v[c] * ratio;
+        m = fmaxf(m, fabsf(v[c]));
+    }
+    return m;
+}
+
+template <int CP>
+__device__ __forceinline__ void feature_band_params(const unsigned *__restrict__ keys, int p, int C, int normalize, float (&bmn)[CP],
+                                                    float (&bden)[CP]) {
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
         bmn[c] = 0.0f; bden[c] = 1.0f;
@@ -205,46 +233,31 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
             bmn[c] = mn; bden[c] = mx - mn;     // (band - min) / (max - min), segment_boundaries.py:16
         }
     }
+}
+
+// K0b: features = [normalize_band] -> [rgb2lab] -> * float32(1/compactness), padded to CP channels (padding is 0:
+// `t = 0 - 0; dc += t*t` leaves every distance bit-identical).  Also reduces max|feature| for the fixed-point scale.
+// Per-band min and (max - min) are hoisted into registers; C % 4 == 0 rasters are read as float4.
+// Pixel-major output [pixel][CP] (quickshift reads its features per pixel).
+template <int CP>
+__global__ __launch_bounds__(256) void features_kernel(const float *__restrict__ src, int Ws, int C,
+                                                       const SrcWindow *__restrict__ wins,
+                                                       const unsigned *__restrict__ keys, int normalize,
+                                                       int to_lab, float ratio, float *__restrict__ feat,
+                                                       unsigned *__restrict__ maxabs_bits) {
+    const int p = blockIdx.y;
+    const SrcWindow wdw = wins[p];
+    float bmn[CP], bden[CP];
+    feature_band_params<CP>(keys, p, C, normalize, bmn, bden);
     const bool vec = (C == CP);                 // C % 4 == 0: aligned float4 reads
     float local_max = 0.0f;
-    (void)npix;
     // blocks walk rows, threads walk the pixels of a row: no integer division per pixel
     for (int y = blockIdx.x; y < wdw.h; y += gridDim.x)
     for (int x = threadIdx.x; x < wdw.w; x += blockDim.x) {
         const long long i = (long long)y * wdw.w + x;
         const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
         float v[CP];
-        if (vec) {
-#pragma unroll
-            for (int q = 0; q < CP / 4; ++q) {
-                const float4 t = reinterpret_cast<const float4 *>(px)[q];
-                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CP; ++c) v[c] = (c < C) ? px[c] : 0.0f;
-        }
-        if (normalize) {
-#pragma unroll
-            for (int c = 0; c < CP; ++c) {
-                float t = (v[c] - bmn[c]) / bden[c];
-                if (!(fabsf(t) <= 3.0e38f)) t = 0.0f;   // constant / non-finite band: the problem is rejected on the host
-                v[c] = t;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CP; ++c) if (!(fabsf(v[c]) <= 3.0e38f)) v[c] = 0.0f;
-        }
-        if (to_lab) {
-            float L, A, B;
-            rgb2lab_f32(v[0], v[1], v[2], L, A, B);
-            v[0] = L; v[1] = A; v[2] = B;
-        }
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            v[c] = v[c] * ratio;
-            local_max = fmaxf(local_max, fabsf(v[c]));
-        }
+        local_max = fmaxf(local_max, feature_pixel<CP>(px, C, vec, normalize, to_lab, ratio, bmn, bden, v));
         float4 *dst = reinterpret_cast<float4 *>(feat + (wdw.pix_off + i) * CP);
 #pragma unroll
         for (int q = 0; q < CP / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -255,6 +268,46 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
     if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits + p, __float_as_uint(local_max));   // one word per window
 }
 
+// The same arithmetic, written as quad-row blocks (slic.hpp: feat_block_f4): a thread owns the four pixels
+// (4q .. 4q+3, x), reads them row by row (each row coalesced across the wave) and writes one float4 per channel
+// (sixteen consecutive threads -> 256 contiguous bytes of a channel run).  Blocks walk quad rows.
+template <int CP>
+__global__ __launch_bounds__(256) void features_planes_kernel(const float *__restrict__ src, int Ws, int C,
+                                                              const SrcWindow *__restrict__ wins,
+                                                              const unsigned *__restrict__ keys, int normalize,
+                                                              int to_lab, float ratio, float *__restrict__ feat,
+                                                              unsigned *__restrict__ maxabs_bits) {
+    const int p = blockIdx.y;
+    const SrcWindow wdw = wins[p];
+    float bmn[CP], bden[CP];
+    feature_band_params<CP>(keys, p, C, normalize, bmn, bden);
+    const bool vec = (C == CP);
+    float local_max = 0.0f;
+    const int QH = (wdw.h + 3) >> 2, XB = (wdw.w + 15) >> 4;
+    float4 *__restrict__ planes = reinterpret_cast<float4 *>(feat) + wdw.feat_off;
+    for (int q = blockIdx.x; q < QH; q += gridDim.x)
+    for (int x = threadIdx.x; x < 16 * XB; x += blockDim.x) {
+        float v[4][CP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 4 * q + i;
+            if (y < wdw.h && x < wdw.w) {
+                const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
+                local_max = fmaxf(local_max, feature_pixel<CP>(px, C, vec, normalize, to_lab, ratio, bmn, bden, v[i]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) v[i][c] = 0.0f;
+            }
+        }
+        float4 *dst = planes + ((long long)q * XB + (x >> 4)) * (CP * 16) + (x & 15);
+#pragma unroll
+        for (int c = 0; c < CP; ++c) dst[c * 16] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
+    if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits + p, __float_as_uint(local_max));
+}
+
 __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ntot) keys[i] = (i < nkeys && (i & 1) == 0) ? 0xffffffffu : 0u;
@@ -263,7 +316,7 @@ __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
 // Launch half of the feature pass on `stream`: min / max of every band of every window, then the features.
 // d_keys layout for np windows: keys[np][C][2] (min, max as ordered uints) | nonfinite[np] | max|feature| bits [np].
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
-                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys) {
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes) {
     if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
     const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + 2 * (size_t)np;
     unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
@@ -279,10 +332,15 @@ int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWin
             hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<1>), dim3(gx, np), dim3(FP_NT), 0, stream, src, Ws, C, d_windows,
                                d_keys, (int *)d_nonfinite);
     }
-    dim3 grid(maxh < 4096 ? maxh : 4096, np);
+    const int rows = planes ? (maxh + 3) / 4 : maxh;
+    dim3 grid(rows < 4096 ? rows : 4096, np);
 #define LAUNCH_FEAT(CPV)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, d_windows, d_keys,   \
-                       normalize, to_lab, ratio, d_feat, d_maxabs)
+    do {                                                                                                                  \
+        if (planes) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, \
+                                       d_windows, d_keys, normalize, to_lab, ratio, d_feat, d_maxabs);                    \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, d_windows,  \
+                                d_keys, normalize, to_lab, ratio, d_feat, d_maxabs);                                      \
+    } while (0)
     switch (CP) {
         case 4: LAUNCH_FEAT(4); break;
         case 8: LAUNCH_FEAT(8); break;
@@ -351,7 +409,8 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     if (!d_keys) return OBIA_E_NOMEM;
     int maxh = 1;
     for (auto &w : b.windows) if (w.h > maxh) maxh = w.h;
-    OBIA_TRY(slic_features_launch(ctx->stream, C, b.CP, np, b.d_windows, maxh, src, Ws, normalize, to_lab, ratio, b.d_feat, d_keys));
+    OBIA_TRY(slic_features_launch(ctx->stream, C, b.CP, np, b.d_windows, maxh, src, Ws, normalize, to_lab, ratio, b.d_feat, d_keys,
+                                  b.feat_planes));
     // one read-back: min/max keys (constant-band check), non-finite flags, max|feature| per window
     std::vector<unsigned> host(ntot);
     OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));

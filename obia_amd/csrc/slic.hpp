@@ -17,21 +17,35 @@ struct SlicProblem {
     int tile_off;        // first workgroup of this problem in the assign grid
     int tiles_x, tiles_y;
     long long pix_off;   // first pixel of this problem in the dense per-problem pixel arrays
+    long long feat_off;  // first float4 of this problem in the feature planes (see feat_block_f4)
+    int XB;              // 16-column blocks per row of the feature planes: ceil(W / 16)
     int n_valid;         // valid (unmasked) pixels
-    int pad;
 };
 
 // Source window of a problem inside the caller's raster (feature preparation).
 struct SrcWindow {
     int y0, x0, h, w;
-    long long pix_off;
+    long long pix_off;   // pixel-major feature layout (quickshift): first pixel
+    long long feat_off;  // quad-row plane layout (SLIC): first float4
 };
+
+// Feature layout of the SLIC sweeps ("quad-row blocks").  Rows are grouped in fours, columns in sixteens; the unit is one
+// float4 = ONE channel of the four pixels (4q .. 4q+3, x):
+//   float4 index = feat_off + ((q * XB + x / 16) * CP + c) * 16 + x % 16            XB = ceil(W / 16)
+// i.e. per (quad row, 16-column block): CP runs of 256 bytes, one per channel -- 4 KB for 8 bands, contiguous.
+// A lane of the sweep owns a vertical 1x4 strip, so one 16-byte load brings a channel of its four pixels as two register
+// pairs (packed-f32 arithmetic on two pixels per instruction), a quarter wave reads 256 contiguous bytes (whole 128-byte
+// lines), the channels of a lane are 256 bytes apart (immediate offsets of one address) and a footprint's quad row is
+// one contiguous block.  Rows past H inside the last quad and columns past W inside the last block hold zeros.
+inline int feat_xb(int w) { return (w + 15) >> 4; }
+inline long long feat_block_f4(int h, int w, int CP) { return (long long)((h + 3) / 4) * feat_xb(w) * CP * 16; }
 
 // regular_grid((1,H,W), n) of scikit-image (util/_regular_grid.py:61-83): start/step per axis,
 // step 0 == slice(None).
 void regular_grid_hw(long long H, long long W, long long n, long long out[4]);
 
 constexpr int SWEEP_TW = 64, SWEEP_TH = 64;   // workgroup tile of the sweep kernel (pixels)
+constexpr int SWEEP_MAXC = 96;   // candidate slots of a sweep tile (LDS slots of the sweep kernel)
 constexpr int CENT_REC = 8;      // header dwords of a centroid record: cy, cx, y0, y1, x0, x1, k, -
 // Accumulator record of one centroid, 128-byte aligned so a tile's flush touches two 64-B lines:
 //   q[0..CP)  colour sums, 64-bit fixed point     q[CP] = n | (sum_y << 32)     q[CP+1] = sum_x
@@ -51,7 +65,9 @@ struct SlicBatch {
     // device arrays (arena)
     SlicProblem *d_probs = nullptr;
     SrcWindow *d_windows = nullptr;
-    float *d_feat = nullptr;           // [total_pix][CP]
+    float *d_feat = nullptr;           // quad-row planes, 4 * total_feat_f4 floats (pixel-major [total_pix][CP] when !feat_planes)
+    bool feat_planes = true;           // false: pixel-major features (quickshift reads them per pixel)
+    long long total_feat_f4 = 0;       // float4 elements of d_feat (plane layout)
     uint8_t *d_mask = nullptr;         // [total_pix] or null
     int32_t *d_labels = nullptr;       // [total_pix] problem-local labels (start_label based)
     float *d_seed = nullptr;           // [total_cent][2]
@@ -73,7 +89,7 @@ struct SlicBatch {
 // skip[p] = 1 (its features are zero) instead of failing the whole batch -- the reference's tiler
 // swallows the per-tile ValueError (tiling.py:149-150).
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
-                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys);
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes = true);
 int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *nonfinite, const unsigned *maxabs_bits, int normalize,
                          std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,

@@ -37,18 +37,28 @@
 namespace obia {
 
 #ifdef OBIA_STAMP
-// Diagnostic build only (make STAMP=1): per-phase wave-cycle sums, written to a buffer no other code reads.
-__device__ unsigned long long g_stamp[16];
-#define STAMP_DECL unsigned long long st_t = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_cnt[6] = {0, 0, 0, 0, 0, 0};
+// Diagnostic build only (tools/build_variant.sh tl -DOBIA_STAMP, tools/timeline_run.py): per-wave timeline, no atomics.
+// Record of a wave (24 qwords, waves of tile t at 4t .. 4t+3): [0..11] phase ticks (s_memtime), [12] start, [13] end,
+// [14] / [15] start / end on the constant 100-MHz clock, [16..21] counters.
+__device__ unsigned long long g_tl[65536 * 4 * 24];
+#define STAMP_DECL unsigned long long st_t = clock64(), st_t0 = st_t, st_r0 = __builtin_amdgcn_s_memrealtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_cnt[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP_COUNT(i, v) st_cnt[i] += (v);
 #define STAMP(i) { const unsigned long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; }
-#define STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int st_i = 0; st_i < 8; ++st_i) atomicAdd(&g_stamp[st_i], st_acc[st_i]); for (int st_i = 0; st_i < 6; ++st_i) atomicAdd(&g_stamp[8 + st_i], st_cnt[st_i]); atomicAdd(&g_stamp[15], 1ull); }
+#define STAMP_FLUSH if (accumulate && (threadIdx.x & 63) == 0 && gtile < 65536) { unsigned long long *st_o = g_tl + ((size_t)gtile * 4 + (threadIdx.x >> 6)) * 24; for (int st_i = 0; st_i < 12; ++st_i) st_o[st_i] = st_acc[st_i]; st_o[12] = st_t0; st_o[13] = clock64(); st_o[14] = st_r0; st_o[15] = __builtin_amdgcn_s_memrealtime(); for (int st_i = 0; st_i < 6; ++st_i) st_o[16 + st_i] = st_cnt[st_i]; }
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_COUNT(i, v)
 #define STAMP_FLUSH
 #endif
+
+typedef float v2f __attribute__((ext_vector_type(2)));   // two pixels of a lane's strip: v_pk_{add,mul}_f32 operate on both at once
+__device__ __forceinline__ v2f splat(float s) { return (v2f){s, s}; }
+
+// one feature of one pixel in the quad-row plane layout (slic.hpp: feat_block_f4) -- rare paths only
+__device__ __forceinline__ float feat_at(const float *__restrict__ feat, const SlicProblem &P, int CP, int y, int x, int ch) {
+    return feat[((P.feat_off + (((long long)(y >> 2) * P.XB + (x >> 4)) * CP + ch) * 16 + (x & 15)) << 2) + (y & 3)];
+}
 
 constexpr int NT = 256;
 constexpr int FB = 16;          // wave footprint side
@@ -62,7 +72,7 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #ifndef OBIA_XCD_GROUP
 #define OBIA_XCD_GROUP 2
 #endif
-constexpr int MAXC = 96;        // LDS candidate slots (two scoring rounds of 64 lanes); must stay <= 128: the slot number
+constexpr int MAXC = SWEEP_MAXC;   // LDS candidate slots (two scoring rounds of 64 lanes); must stay <= 128: the slot number
                                 // rides in the low 7 bits of the scoring keys
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
@@ -182,7 +192,9 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
     OBIA_WAVE_REDUCE("v_min_u32_dpp");   // every lane now holds the minimum of its row of 16
     const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
     const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return min(min(a, b), min(c, d));
+    unsigned r;   // the four row minima meet on the scalar unit (hipcc would move them back to vector registers for a v_min3)
+    asm("s_min_u32 %0, %1, %2\n\ts_min_u32 %0, %0, %3\n\ts_min_u32 %0, %0, %4" : "=&s"(r) : "s"(a), "s"(b), "s"(c), "s"(d) : "scc");
+    return r;
 }
 
 // LDS written by some lanes of a wave and read by other lanes of the same wave: the LDS pipe executes a
@@ -223,7 +235,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
         if (MASKED && mask[pix] == 0) { labels[pix] = start_label - 1; continue; }
         float f[CP];
 #pragma unroll
-        for (int ch = 0; ch < CP; ++ch) f[ch] = feat[pix * CP + ch];
+        for (int ch = 0; ch < CP; ++ch) f[ch] = feat_at(feat, P, CP, y, x, ch);
         int by_lo = (y - 2 * P.sy - 2) / P.sy; if (y - 2 * P.sy - 2 < 0) by_lo = 0;
         int by_hi = (y + 2 * P.sy + 2) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
         int bx_lo = (x - 2 * P.sx - 2) / P.sx; if (x - 2 * P.sx - 2 < 0) bx_lo = 0;
@@ -280,6 +292,9 @@ __device__ __forceinline__ void slic_assign_body(
     // colours are folded by every sweep that runs this body without LEAN (the colour sweeps and the last pre-pass sweep)
     // and by none that runs it with LEAN: a compile-time constant either way
     constexpr int accum_color = LEAN ? 0 : 1;
+#ifdef OBIA_ABL_NOACC
+    accumulate = 0;   // ablation build: no centroid update at all
+#endif
     // accumulate: fold this sweep's assignment into the accumulator records (off on the very last sweep);
     // accum_color: also fold the colours (off on the spatial-only pre-pass sweeps whose colour means are never
     // read: only the LAST pre-pass sweep seeds the colours of the main pass, slic_superpixels.py:310-318)
@@ -293,10 +308,11 @@ __device__ __forceinline__ void slic_assign_body(
     constexpr int XG = OBIA_XCD_GROUP;   // consecutive tiles that share an XCD
     const int gtile = (((int)(blockIdx.x >> 3) / XG) * 8 + (int)(blockIdx.x & 7)) * XG + (int)(blockIdx.x >> 3) % XG;
     if (gtile >= total_tiles_all) return;
+    STAMP_DECL
+    constexpr int RS = CENT_REC + CP;
     const int prob_i = tile_prob[gtile];
     const SlicProblem P = probs[prob_i];
     const int tile = gtile - P.tile_off;
-    constexpr int RS = CENT_REC + CP;
     constexpr int AQ = LEAN ? 1 : CP + 1;       // qwords of an LDS accumulator: colours (not in the lean kernel), then one packed word
     constexpr int PWI = LEAN ? 0 : CP;          // index of the packed word
                                                 //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 64x64 tile: n <= 4096 < 2^16,
@@ -305,6 +321,11 @@ __device__ __forceinline__ void slic_assign_body(
     const float fs = (float)fscale;             // power of two
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
+    // slot = where staging happened to put a candidate; rank = its position in ascending k (the reference's tie rule, lowest k
+    // wins, becomes a comparison of ranks: the rank rides in the low word of the pixel keys and indexes the accumulators)
+    __shared__ __attribute__((aligned(16))) int s_k[MAXC];   // slot -> k
+    __shared__ int s_rank[MAXC];                             // slot -> rank
+    __shared__ int s_kr[MAXC];                               // rank -> k
     __shared__ unsigned long long s_acc[MAXC][AQ];
     // transposed scratch of the fold: [wave][layer = first / second run of a lane][field = colours, packed integer word][lane]
     constexpr int NF = LEAN ? 1 : CP + 1;
@@ -319,22 +340,27 @@ __device__ __forceinline__ void slic_assign_body(
     __shared__ int s_tkey[LEAN ? 1 : NT / 64][FLD][LEAN ? 1 : 64];
     __shared__ unsigned s_orph[SWEEP_TH * SWEEP_TW / 32];   // valid pixels no window reached (rare): handled after the footprints
     __shared__ int s_cnt, s_uncacheable;
+#ifdef OBIA_ABL_LDSPAD
+    __shared__ int s_pad[OBIA_ABL_LDSPAD / 4];   // ablation build: LDS ballast that limits the workgroups per CU
+    if (start_label == 12345) s_pad[threadIdx.x] = 1;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it lives in scalar registers
     const int ty0 = (tile / P.tiles_x) * SWEEP_TH, tx0 = (tile % P.tiles_x) * SWEEP_TW;
     const int ty1 = min(ty0 + SWEEP_TH, P.H), tx1 = min(tx0 + SWEEP_TW, P.W);
 
-    STAMP_DECL
     // ---- wave geometry; the features of the wave's FIRST footprint are requested before staging, so their HBM
     // latency overlaps the dependent bin -> record loads of the staging phase ---------------------------------------
     const float w = P.spatial_w;
     const int fy0 = ty0 + FB * wv;
+    const int fy0_o = fy0;
     const bool wave_active = fy0 < P.H;   // a wave below the bottom edge only helps with the final flush
     const int fy1 = min(fy0 + FB, P.H);
+    const int fy1_o = fy1;
     const int yb = fy0 + PPT * (lane >> 4);
     const bool want_feat = !IGNORE_COLOR || accum_color;
-    float f[PPT][LEAN ? 1 : CP];
+    v2f f2[LEAN ? 1 : CP][PPT / 2];   // [channel][row pair]: pixels (yb, yb+1) and (yb+2, yb+3) of the lane's strip
     unsigned char mb[PPT];    // mask bytes of the lane's four pixels (turned into `valid` at the label stage: nothing waits for them earlier)
     // Addresses: one wave-uniform 64-bit base per footprint (scalar registers) plus a 32-bit lane offset -- a pixel's
     // address costs one or two vector instructions instead of a 64-bit multiply-add chain (16 rows x W x 32 B fits 32
@@ -346,32 +372,37 @@ __device__ __forceinline__ void slic_assign_body(
     // fold, the next scoring and the first selection run under the memory latency.  `real` = false (no next footprint):
     // every lane reads the first pixel of the current footprint -- one cache line, no branch around the loads.
     const unsigned lrow = (unsigned)(PPT * (lane >> 4)) * (unsigned)P.W + (unsigned)(lane & 15);   // pixel 0 of the strip, relative to (fy0, fx0)
-    auto fetch = [&](int fx0, int yb, unsigned lrow, bool real) {   // (row base and offset come in as opaque per-footprint copies)
-        const int xx = fx0 + (lane & 15);
+    auto fetch = [&](int fx0, int yb, unsigned lrow, int lane_o, bool real) {   // (row base and offset come in as opaque per-footprint copies)
+#ifdef OBIA_ABL_NOLOAD
+        real = false;   // ablation build: every lane reads the footprint's first pixel (no HBM traffic for features / mask)
+#endif
+        const int xx = fx0 + (lane_o & 15);
         const long long fbase = P.pix_off + (long long)fy0 * P.W + fx0;      // wave-uniform
         const uint8_t *mbase = mask + (MASKED ? fbase : 0);
-        const char *fbase_p = reinterpret_cast<const char *>(feat + fbase * (LEAN ? 0 : CP));
         unsigned off[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) off[j] = (real && (yb + j < P.H) && (xx < P.W)) ? lrow + (unsigned)j * (unsigned)P.W : 0u;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) mb[j] = MASKED ? mbase[off[j]] : (unsigned char)1;
+        if (!LEAN && want_feat) {
+            // quad-row blocks (slic.hpp): ONE 16-byte load per channel brings that channel of the lane's four pixels, the
+            // channels are 256 bytes apart (immediate offsets), a quarter wave reads 256 contiguous bytes and the footprint's
+            // quad row is one contiguous block (fy0 and fx0 are multiples of 16: the lane's strip is one quad row of one block)
+            const float4 *pb = reinterpret_cast<const float4 *>(feat) +
+                               (P.feat_off + ((long long)(fy0 >> 2) * P.XB + (fx0 >> 4)) * ((LEAN ? 0 : CP) * 16));   // wave-uniform
+            const unsigned fob = (real && (yb < P.H) && (xx < P.W))
+                                     ? ((unsigned)(lane_o >> 4) * (unsigned)((LEAN ? 0 : CP) * 16 * P.XB) + (unsigned)(lane_o & 15)) * 16u : 0u;
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            if (!LEAN && want_feat) {
-                const float4 *src = reinterpret_cast<const float4 *>(fbase_p + (size_t)(off[j] * (unsigned)(CP * 4)));
-#pragma unroll
-                for (int q = 0; q < CP / 4; ++q) {
-                    const float4 t = src[q];
-                    f[j][4 * q] = t.x; f[j][4 * q + 1] = t.y; f[j][4 * q + 2] = t.z; f[j][4 * q + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < (LEAN ? 1 : CP); ++c) f[j][c] = 0.0f;
+            for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) {
+                const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pb + ch * 16) + (size_t)fob);
+                f2[ch][0] = (v2f){t.x, t.y};
+                f2[ch][1] = (v2f){t.z, t.w};
             }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) { f2[ch][0] = splat(0.0f); f2[ch][1] = splat(0.0f); }
         }
     };
-    if (!FIXPT && wave_active) fetch(tx0, yb, lrow, true);
     constexpr int GQ = CP + 3;   // global record / cache entry: colours, n, sum_y, sum_x
     const int tile_id = P.tile_off + tile;
     // bins whose centroids can reach the tile: candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with
@@ -415,34 +446,33 @@ __device__ __forceinline__ void slic_assign_body(
     if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
     __syncthreads();
 
-    if (FIXPT && wave_active) fetch(tx0, yb, lrow, true);
-
-    auto do_stage = [&]() {
-    // ---- 1. stage the candidates of the tile ---------------------------------------------------------------
-    {
-        for (int bi = tid; bi < nbins; bi += NT) {
-            int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
-            while (cur >= 0) {
-                // one round trip per list node: the whole header and the link are requested together
-                const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
-                const float4 r0 = src[0], r1 = src[1];   // header only: the colours are read at visit time (scalar loads)
-                const int nxt = next[cur];
-                const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
-                const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
-                if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
-                    const int slot = atomicAdd(&s_cnt, 1);
-                    if (slot < MAXC) {
-                        float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
-                        dh[0] = r0; dh[1] = r1;
-                    }
+    // ---- 1. stage the candidates of the tile: lanes walk the lists of the bins whose centroids can reach it ------------------
+    // (the features of the wave's FIRST footprint are requested first: their HBM latency overlaps the dependent
+    // bin -> record loads)
+    if (wave_active) fetch(tx0, yb, lrow, lane, true);
+    for (int bi = tid; bi < nbins; bi += NT) {
+        int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
+        while (cur >= 0) {
+            // one round trip per list node: the header and the link are requested together (the colours are read at visit
+            // time by the scalar unit)
+            const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
+            const float4 r0 = src[0], r1 = src[1];
+            const int nxt = next[cur];
+            const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
+            const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
+            if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < MAXC) {
+                    float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
+                    dh[0] = r0; dh[1] = r1;
+                    s_k[slot] = cur;
                 }
-                cur = nxt;
             }
+            cur = nxt;
         }
     }
     __syncthreads();
-    };
-    do_stage();
+    STAMP(1)   // prologue + staging (up to its barrier)
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
         slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
@@ -450,37 +480,27 @@ __device__ __forceinline__ void slic_assign_body(
         return;
     }
     auto do_sort = [&]() {
-    // sort the slots by centroid index: slot order == k order, so the reference's tie rule (lowest k wins) is a
-    // comparison of slot numbers and rides in the low word of the pixel keys.  rank = number of smaller k (all distinct).
-    // Waves 0 and 1 hold the k of all slots in two registers (slot = lane, lane + 64) and thread t ranks slot t against
-    // them: a readlane, a compare and an add per slot, no dependent LDS reads.
+    // rank of every slot = number of staged candidates with a smaller k (all distinct).  Thread t ranks slot t against the whole
+    // k table with broadcast reads of four entries each -- independent LDS reads, no serial chain; the records stay where they are.
     {
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        int rank = -1;
-        if (64 * wv < nc) {   // wave-uniform: the waves that own slots (MAXC <= 128: waves 0 and 1)
-            const int k0 = (lane < nc) ? __float_as_int(s_hdr[lane][6]) : 0x7fffffff;
-            const int k1 = (lane + 64 < nc) ? __float_as_int(s_hdr[lane + 64][6]) : 0x7fffffff;
-            if (tid < nc) {
-                r0 = *reinterpret_cast<const float4 *>(&s_hdr[tid][0]);
-                r1 = *reinterpret_cast<const float4 *>(&s_hdr[tid][4]);
-            }
-            const int myk = (wv == 0) ? k0 : k1;
+        if (tid < nc) {
+            const int myk = s_k[tid];
             int r = 0;
-            const int n0 = nc < 64 ? nc : 64;
-            for (int i = 0; i < n0; ++i) r += (__builtin_amdgcn_readlane(k0, i) < myk) ? 1 : 0;
-            for (int i = 64; i < nc; ++i) r += (__builtin_amdgcn_readlane(k1, i - 64) < myk) ? 1 : 0;
-            if (tid < nc) rank = r;
-        }
-        __syncthreads();
-        if (rank >= 0) {
-            *reinterpret_cast<float4 *>(&s_hdr[rank][0]) = r0;
-            *reinterpret_cast<float4 *>(&s_hdr[rank][4]) = r1;
+            for (int i = 0; i < nc; i += 4) {
+                const int4 kq = *reinterpret_cast<const int4 *>(&s_k[i]);
+                r += (kq.x < myk) ? 1 : 0;
+                r += (i + 1 < nc && kq.y < myk) ? 1 : 0;
+                r += (i + 2 < nc && kq.z < myk) ? 1 : 0;
+                r += (i + 3 < nc && kq.w < myk) ? 1 : 0;
+            }
+            s_rank[tid] = r;
+            s_kr[r] = myk;
         }
         __syncthreads();
     }
     };
     do_sort();
-    STAMP(0)   // staging
+    STAMP(0)   // sort
 
     constexpr unsigned INF_BITS = 0x7f800000u;
     // ---- 2. per wave: four 16x16 footprints (one 16-row band of the 64x64 tile) ---------------------------------------
@@ -500,9 +520,8 @@ __device__ __forceinline__ void slic_assign_body(
         // is d < inf.  Masked / outside pixels are evaluated like the others (their features are zeros or unused values)
         // and discarded at the label stage: the visits never wait for the mask bytes.
         unsigned long long bk[PPT];
-        float fyv[PPT];
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) { bk[j] = (unsigned long long)INF_BITS << 32; fyv[j] = (float)(yb_i + j); }
+        for (int j = 0; j < PPT; ++j) bk[j] = (unsigned long long)INF_BITS << 32;
 #define BK_D(j) __uint_as_float((unsigned)(bk[j] >> 32))
 
         // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
@@ -517,6 +536,10 @@ __device__ __forceinline__ void slic_assign_body(
             const int c = 64 * r + lane_i;
             key[r] = 0xffffffffu;
             kkv[r] = 0;
+            // (the float images of the footprint's edges are rebuilt here from scalar registers: kept across the
+            // footprint loop they cost vector registers the visit loop needs)
+            int fy0 = fy0_o, fy1 = fy1_o;
+            asm volatile("" : "+s"(fy0), "+s"(fy1));
             if (c < nc) {
                 const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
                 const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
@@ -529,7 +552,7 @@ __device__ __forceinline__ void slic_assign_body(
                     const float rx = (cx < (float)fx0) ? (float)fx0 : ((cx > (float)(fx1 - 1)) ? (float)(fx1 - 1) : cx);
                     const float tyv = cy - ry, txv = cx - rx;
                     const float lb = (tyv * tyv + txv * txv) * w;
-                    key[r] = (__float_as_uint(lb) & ~127u) | (unsigned)c;      // lb >= 0 and finite: never 0xffffffff
+                    key[r] = (__float_as_uint(lb) & ~127u) | (unsigned)s_rank[c];      // lb >= 0 and finite: never 0xffffffff
                 }
             }
         }
@@ -538,84 +561,112 @@ __device__ __forceinline__ void slic_assign_body(
         STAMP_COUNT(0, 1)   // footprints
         // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
         // a lane's largest current best distance (+inf while one of its valid pixels is unassigned, 0 when it has no
-        // valid pixel): the walk stops when lb exceeds it in every lane -- one compare and a ballot, no wave reduction
+        // valid pixel): the walk stops when lb exceeds it in every lane -- one compare and a ballot, no wave reduction.
+        // The kernel is bound by the dependent chain of a single wave, not by instruction issue (a wave alone on its SIMD
+        // needs 2/3 of the time it needs with five neighbours), so an iteration is ONE straight-line block as far as
+        // possible: the record is requested from LDS first, the wave minimum that names the NEXT candidate is computed
+        // under that latency, the window test is applied by selects, and the two row pairs run as two interleaved chains.
         float mybest = fmaxf(fmaxf(BK_D(0), BK_D(1)), fmaxf(BK_D(2), BK_D(3)));
+#ifdef OBIA_ABL_VISITS
+        int abl_visits = 0;
+#endif
+        unsigned mn = wave_umin(min(key[0], key[1]));
         for (;;) {
-            const unsigned mn = wave_umin(min(key[0], key[1]));
             if (mn == 0xffffffffu) break;
             if (!__ballot(__uint_as_float(mn & ~127u) <= mybest)) break;   // equality must still be visited: it can tie on k
-            const int c = (int)(mn & 127u);
+#ifdef OBIA_ABL_VISITS
+            if (++abl_visits > OBIA_ABL_VISITS) break;   // ablation build: at most this many visits per footprint
+#endif
+            const unsigned c = mn & 127u;   // rank of the candidate: low word of the pixel keys
+            // the scoring lane that holds the minimum names the candidate: its record is read from global memory at a
+            // wave-uniform address -- the scalar unit loads header and colours into SGPRs, no VALU / LDS work (the kernel is
+            // bound by VALU issue: every vector instruction of this loop is paid 4.4 times per footprint)
+            const unsigned long long m0 = __ballot(key[0] == mn), m1 = __ballot(key[1] == mn);
+            const int kk = m0 ? __builtin_amdgcn_readlane(kkv[0], (int)__builtin_ctzll(m0)) : __builtin_amdgcn_readlane(kkv[1], (int)__builtin_ctzll(m1));
             key[0] = (key[0] == mn) ? 0xffffffffu : key[0];
             key[1] = (key[1] == mn) ? 0xffffffffu : key[1];
-            // the candidate's record is read from global memory at a wave-uniform address (its index is lifted out of the
-            // scoring lane with one readlane): the scalar unit loads header and colours into SGPRs, no VALU / LDS work
-            const int kk = (c & 64) ? __builtin_amdgcn_readlane(kkv[1], c & 63) : __builtin_amdgcn_readlane(kkv[0], c & 63);
             const float4 *__restrict__ crec = reinterpret_cast<const float4 *>(cent + (size_t)kk * RS);
             const float4 h0 = crec[0], h1 = crec[1];
+            // the next candidate, under the latency of the loads
+            const unsigned mn_next = wave_umin(min(key[0], key[1]));
             const float cy = h0.x, cx = h0.y;
             const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
             const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
+            const float mdc = SLICZERO ? h1.w : 1.0f;
+            mn = mn_next;
+            STAMP(8)   // visit: record + next minimum
             const float tx = cx - fx;
             const float dx2 = tx * tx;
-            float dv[PPT];
+            // rows of the strip as floats, rebuilt per visit from the one integer register that is live anyway (row numbers
+            // are far below 2^24: float(yb) + j is exact)
+            int yb_v = yb_i;
+            asm volatile("" : "+v"(yb_v));
+            const float fyb = (float)yb_v;
+            v2f dv2[PPT / 2];
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const float tyv = cy - fyv[j];
-                const float dy2 = tyv * tyv;
-                dv[j] = (dy2 + dx2) * w;           // (dz + dy + dx) * spatial_weight, dz = 0
+            for (int p = 0; p < PPT / 2; ++p) {   // two pixels per instruction; each component rounds like the scalar operation
+                const v2f tyv = splat(cy) - (splat(fyb) + (v2f){(float)(2 * p), (float)(2 * p + 1)});
+                const v2f dy2 = tyv * tyv;
+                dv2[p] = (dy2 + splat(dx2)) * splat(w);           // (dz + dy + dx) * spatial_weight, dz = 0
             }
-            // a window that covers the whole footprint (the common case: windows are ~4S wide) needs no per-pixel test;
-            // otherwise a pixel outside the window gets the spatial term +inf: `inf < best` never holds, it cannot win
-            if (!((y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1))) {   // wave-uniform
+            float dv[PPT] = {dv2[0].x, dv2[0].y, dv2[1].x, dv2[1].y};
+            // a window that covers the whole footprint needs no per-pixel test; otherwise a pixel outside the window gets the
+            // spatial term +inf: `inf < best` never holds, it cannot win
+            if (!((y0 <= fy0) && (y1 >= fy1) && (x0 <= fx0) && (x1 >= fx1))) {   // wave-uniform, decided on the scalar unit
                 const bool inx = (x >= x0) && (x < x1);
 #pragma unroll
                 for (int j = 0; j < PPT; ++j)
-                    dv[j] = (inx && ((unsigned)(yb_i + j - y0) < (unsigned)(y1 - y0))) ? dv[j] : INFINITY;
+                    dv[j] = (inx && ((unsigned)(yb_v + j - y0) < (unsigned)(y1 - y0))) ? dv[j] : INFINITY;
             }
             // colour >= 0 and float add is monotone, so d >= spatial: a candidate whose spatial part already exceeds the best
-            // distance of a pixel cannot win it (equality could still tie on k).  Only the wave-level ballots of that test
-            // are kept: they decide which j-slices evaluate colours at all; the key comparison below needs no mask
-            // (spatial > best  =>  d > best  =>  new key > key).
-            unsigned long long live[PPT];
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) live[j] = __ballot(!(dv[j] > BK_D(j)));
+            // distance of a pixel cannot win it (equality could still tie on k): no such pixel in the wave -> no colours
+            const bool anylive = !(dv[0] > BK_D(0)) || !(dv[1] > BK_D(1)) || !(dv[2] > BK_D(2)) || !(dv[3] > BK_D(3));
             STAMP_COUNT(1, 1)   // visits
-            STAMP_COUNT(4, __popcll(live[0]) + __popcll(live[1]) + __popcll(live[2]) + __popcll(live[3]))
-            if (!(live[0] | live[1] | live[2] | live[3])) continue;
+            STAMP(9)   // visit: spatial + live test
+            if (!__ballot(anylive)) continue;
             STAMP_COUNT(2, 1)   // visits that evaluate colours
-            float col[LEAN ? 1 : CP];
-            if (!IGNORE_COLOR) {
-#pragma unroll
-                for (int q = 0; q < CP / 4; ++q) {
-                    const float4 t = crec[2 + q];   // wave-uniform address: scalar loads, the colours stay in SGPRs
-                    col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                // the strip is vertical: a candidate above or below the footprint only reaches a few rows, so whole
-                // j-slices of the wave have no live lane and skip the colour arithmetic (wave-uniform branch)
-                if (!live[j]) continue;
-                STAMP_COUNT(3, 1)
-                float d = dv[j];
+            STAMP_COUNT(3, 2)
+            {
+                float col[LEAN ? 1 : CP];
                 if (!IGNORE_COLOR) {
-                    float dc = 0.0f;
 #pragma unroll
-                    for (int ch = 0; ch < CP; ++ch) {
-                        const float t = f[j][LEAN ? 0 : ch] - col[LEAN ? 0 : ch];
-                        dc += t * t;
+                    for (int q = 0; q < CP / 4; ++q) {
+                        const float4 t = crec[2 + q];   // wave-uniform address: scalar loads, the colours stay in SGPRs
+                        col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
+                    }
+                }
+                v2f d0 = (v2f){dv[0], dv[1]}, d1 = (v2f){dv[2], dv[3]};
+                if (!IGNORE_COLOR) {
+                    // dc = 0; dc += t*t per channel, in channel order: 0 + t*t == t*t exactly (t*t is never -0), the other
+                    // additions stay sequential.  Packed f32: both pixels of a pair in one v_pk_add / v_pk_mul, each
+                    // component rounded like the scalar instruction (no contraction: -ffp-contract=off); the two pairs
+                    // are independent chains in one block.
+                    v2f t0 = f2[0][0] - splat(col[0]), t1 = f2[0][1] - splat(col[0]);
+                    v2f dc0 = t0 * t0, dc1 = t1 * t1;
+#pragma unroll
+                    for (int ch = 1; ch < (LEAN ? 1 : CP); ++ch) {
+                        t0 = f2[LEAN ? 0 : ch][0] - splat(col[LEAN ? 0 : ch]);
+                        t1 = f2[LEAN ? 0 : ch][1] - splat(col[LEAN ? 0 : ch]);
+                        dc0 += t0 * t0;
+                        dc1 += t1 * t1;
                     }
                     // SLIC-zero: the colour term is scaled by the largest colour distance seen in this cluster so far
                     // (_slic.pyx: dist_center += dist_color / max_dist_color[k])
-                    d += SLICZERO ? dc / h1.w : dc;
+                    d0 += SLICZERO ? dc0 / splat(mdc) : dc0;
+                    d1 += SLICZERO ? dc1 / splat(mdc) : dc1;
                 }
                 // reference: ascending k with strict `distance > d`  ==  lexicographic min of (d, k)  ==  min of the keys
-                const unsigned long long nk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)c;
-                bk[j] = (nk < bk[j]) ? nk : bk[j];
+                const float dd[PPT] = {d0.x, d0.y, d1.x, d1.y};
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const unsigned long long nk = ((unsigned long long)__float_as_uint(dd[j]) << 32) | (unsigned long long)c;
+                    bk[j] = (nk < bk[j]) ? nk : bk[j];
+                }
             }
             mybest = fmaxf(fmaxf(BK_D(0), BK_D(1)), fmaxf(BK_D(2), BK_D(3)));
+            STAMP(10)   // visit: colours + keys
         }
-        STAMP(3)   // visits
+        STAMP(3)   // visits (loop control, first minimum)
 
         // ---- labels ---------------------------------------------------------------------------------------------------
         int pk[PPT];   // accumulation key: LDS slot, or -1
@@ -626,11 +677,6 @@ __device__ __forceinline__ void slic_assign_body(
         // stores and four LDS reads per lane) -- an orphan then raises a flag and the host repeats the batch with every
         // sweep storing (slic_run_sweeps): the result is the same either way.
         bool valid[PPT];
-        int kslot[PPT];
-        if (store_labels) {   // kernel argument: wave-uniform
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) kslot[j] = __float_as_int(s_hdr[(unsigned)bk[j]][6]);   // four LDS reads in flight (slot 0 while unassigned)
-        }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const bool inimg = (yb_i + j < P.H) && (x < P.W);
@@ -640,11 +686,17 @@ __device__ __forceinline__ void slic_assign_body(
             // a valid pixel no window reaches keeps the previous sweep's label (`nearest` is only initialised once,
             // before the loop): nothing is stored, the pixel is noted in the tile's bitmap and accumulated under its old
             // label after the footprints (rare: centroids that drifted away from a thin piece of the mask)
-            const bool orph = valid[j] && !assigned;
-            orphan |= orph;
-            if (store_labels && inimg && !orph)
-                __builtin_nontemporal_store(assigned ? kslot[j] - P.cent_off + start_label : start_label - 1,
-                                            lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
+            orphan |= valid[j] && !assigned;
+        }
+        if (store_labels) {   // kernel argument: wave-uniform
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const bool inimg = (yb_i + j < P.H) && (x < P.W);
+                const int kk = s_kr[(unsigned)bk[j]];   // rank -> k (rank 0 while unassigned: unused)
+                if (inimg && !(valid[j] && pk[j] < 0))
+                    __builtin_nontemporal_store(pk[j] >= 0 ? kk - P.cent_off + start_label : start_label - 1,
+                                                lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
+            }
         }
         if (__ballot(orphan)) {   // wave-uniform, rare
             if (!store_labels && lane_i == 0) *orphan_flag = 1;   // the labels this pixel would keep were not stored: repeat the batch
@@ -706,7 +758,7 @@ __device__ __forceinline__ void slic_assign_body(
                     pw += 1u | ((unsigned)(yb_i + j - ty0) << 8) | (xrel << 20);
                     if (!LEAN && accum_color) {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) rf[LEAN ? 0 : ch] += to_fixed32(f[j][LEAN ? 0 : ch], fs);
+                        for (int ch = 0; ch < CP; ++ch) rf[LEAN ? 0 : ch] += to_fixed32((j & 1) ? f2[LEAN ? 0 : ch][j >> 1].y : f2[LEAN ? 0 : ch][j >> 1].x, fs);
                     }
                 }
             }
@@ -716,7 +768,7 @@ __device__ __forceinline__ void slic_assign_body(
         STAMP(5)   // run merge
         {   // the feature registers are free: request the next footprint (the ONLY call site inside the loop)
             const bool has_next = (bxi + 1 < SWEEP_TW / FB) && (fx0 + FB < P.W);   // wave-uniform
-            fetch(has_next ? fx0 + FB : fx0, yb_i, lrow_i, has_next);
+            fetch(has_next ? fx0 + FB : fx0, yb_i, lrow_i, lane_i, has_next);
         }
         if (!accumulate || FOLD_LAYERS == 0) continue;
         // transposed fold.  Colours: lane (fld, g) walks the strips 8g .. 8g+7 of colour field fld, layer by layer.  The packed
@@ -733,11 +785,14 @@ __device__ __forceinline__ void slic_assign_body(
                     for (int layer = 0; layer < FOLD_LAYERS; ++layer) {
                         int cur = -1;
                         long long sum = 0;
+                        // all sixteen reads first (independent addresses): one LDS round trip, not eight behind the atomics
+                        int tkv[8], vv[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { tkv[i] = s_tkey[wv][layer][8 * g + i]; vv[i] = s_tf[wv][layer][LEAN ? 0 : fld][8 * g + i]; }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const int src = 8 * g + i;
-                            const int tk = s_tkey[wv][layer][src];
-                            const int v = s_tf[wv][layer][LEAN ? 0 : fld][src];   // stale where tk < 0: never added
+                            const int tk = tkv[i];
+                            const int v = vv[i];   // stale where tk < 0: never added
                             if (tk != cur) {
                                 if (cur >= 0) atomicAdd(&s_acc[cur][LEAN ? 0 : fld], (unsigned long long)sum);
                                 cur = tk; sum = 0;
@@ -757,11 +812,14 @@ __device__ __forceinline__ void slic_assign_body(
                 atomicAdd(&s_acc[cur][PWI], (unsigned long long)(sum & 0xffu) | ((unsigned long long)((sum >> 8) & 0xfffu) << 16) |
                                                 ((unsigned long long)(sum >> 20) << 40));
             };
+            int tkv[8];
+            unsigned vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { tkv[i] = s_tkey[wv][layer][8 * g + i]; vv[i] = (unsigned)s_tf[wv][layer][NF - 1][8 * g + i]; }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int src = 8 * g + i;
-                const int tk = s_tkey[wv][layer][src];
-                const unsigned v = (unsigned)s_tf[wv][layer][NF - 1][src];
+                const int tk = tkv[i];
+                const unsigned v = vv[i];
                 if (tk != cur) {
                     if (cur >= 0) emit();
                     cur = tk; sum = 0;
@@ -785,7 +843,7 @@ __device__ __forceinline__ void slic_assign_body(
             if (prev < start_label) continue;
             float one[CP];
 #pragma unroll
-            for (int ch = 0; ch < CP; ++ch) one[ch] = accum_color ? feat[pix * CP + ch] : 0.0f;
+            for (int ch = 0; ch < CP; ++ch) one[ch] = accum_color ? feat_at(feat, P, CP, y, x, ch) : 0.0f;
             global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, (unsigned)y, (unsigned)x, one, fs);
         }
     }
@@ -800,9 +858,9 @@ __device__ __forceinline__ void slic_assign_body(
         const int slot = i / QN, q = QLO + (i - slot * QN);
         const unsigned long long pw = s_acc[slot][PWI];
         const unsigned long long n = pw & 0xffffull;
-        if (FIXPT && keep && q == QLO) ck[1 + slot] = n ? __float_as_int(s_hdr[slot][6]) : -1;
+        if (FIXPT && keep && q == QLO) ck[1 + slot] = n ? s_kr[slot] : -1;
         if (n == 0ull) continue;   // nothing landed on this centroid
-        const int k = __float_as_int(s_hdr[slot][6]);
+        const int k = s_kr[slot];
         unsigned long long v;
         if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][LEAN ? 0 : q] : 0ull; }
         else if (q == CP) v = n;
@@ -842,9 +900,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LEAN_WAVES, 
 }
 
 #ifdef OBIA_STAMP
-extern "C" void obia_debug_stamps(unsigned long long *out16, int reset) {
-    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+extern "C" void obia_debug_timeline(unsigned long long *out, int nwaves) {   // 24 qwords per wave, waves of tile t at 4t .. 4t+3
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * 24 * (size_t)nwaves);
 }
 #endif
 
@@ -867,14 +924,9 @@ __global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__
             const float *rec = cent + (size_t)k * RS;
             float dc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < CP / 4; ++q) {
-                const float4 f = reinterpret_cast<const float4 *>(feat + pix * CP)[q];
-                const float4 c = reinterpret_cast<const float4 *>(rec + CENT_REC)[q];
-                float t;
-                t = f.x - c.x; dc += t * t;
-                t = f.y - c.y; dc += t * t;
-                t = f.z - c.z; dc += t * t;
-                t = f.w - c.w; dc += t * t;
+            for (int ch = 0; ch < CP; ++ch) {
+                const float t = feat_at(feat, P, CP, y, x, ch) - rec[CENT_REC + ch];
+                dc += t * t;
             }
             unsigned *slot = reinterpret_cast<unsigned *>(cent + (size_t)k * RS + 7);
             if (__float_as_uint(dc) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(dc));

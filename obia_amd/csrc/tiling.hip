@@ -294,19 +294,21 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.max_iter = S.sp.max_num_iter;
     b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
     b.slic_zero = S.sp.slic_zero != 0;
-    long long off = 0, maxpix = 1;
+    long long off = 0, foff = 0, maxpix = 1;
     b.probs.resize(np);
     b.windows.resize(np);
     for (int p = 0; p < np; ++p) {
         wins[p].pix_off = off;
         SlicProblem P{};
-        P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off;
+        P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off; P.feat_off = foff; P.XB = feat_xb(wins[p].w);
         b.probs[p] = P;
-        b.windows[p] = SrcWindow{wins[p].y0, wins[p].x0, wins[p].h, wins[p].w, off};
+        b.windows[p] = SrcWindow{wins[p].y0, wins[p].x0, wins[p].h, wins[p].w, off, foff};
         const long long n = (long long)wins[p].h * wins[p].w;
         if (n > maxpix) maxpix = n;
         off += n;
+        foff += feat_block_f4(wins[p].h, wins[p].w, b.CP);
     }
+    b.total_feat_f4 = foff;
     if (off > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
     b.total_pix = off;
     TileWin *d_wins = A.get<TileWin>(np);
@@ -320,9 +322,11 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
             const TileWin &a = S.pf.wins[S.pf.cursor + p];
             if (a.y0 != wins[p].y0 || a.x0 != wins[p].x0 || a.h != wins[p].h || a.w != wins[p].w) { set_error("white batch does not match the prefetched windows"); return OBIA_E_INVALID; }
         }
-        b.d_feat = S.pf.d_feat + (size_t)S.pf.windows[S.pf.cursor].pix_off * b.CP;
+        // (the prefetched planes of these windows lie back to back in the same order: the batch's feat_off values, which
+        // start at 0, are offsets from the first window's block)
+        b.d_feat = S.pf.d_feat + 4 * (size_t)S.pf.windows[S.pf.cursor].feat_off;
     } else {
-        b.d_feat = A.get<float>((size_t)off * b.CP);
+        b.d_feat = A.get<float>(4 * (size_t)foff);
     }
     b.d_labels = A.get<int32_t>((size_t)off);
     int32_t *d_final = A.get<int32_t>((size_t)off);
@@ -475,22 +479,23 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
         }
     const size_t NP = pf.wins.size();
     if (NP == 0) return OBIA_OK;
-    long long off = 0;
+    long long off = 0, foff = 0;
+    const int CP = (S.C + 3) & ~3;
     pf.windows.resize(NP);
     for (size_t p = 0; p < NP; ++p) {
         const TileWin &t = pf.wins[p];
         if (t.y0 < 0 || t.y0 + t.h > S.H) { pf = TileState::PreFeat(); return OBIA_OK; }   // the batches report the halo error
-        pf.windows[p] = SrcWindow{t.y0, t.x0, t.h, t.w, off};
+        pf.windows[p] = SrcWindow{t.y0, t.x0, t.h, t.w, off, foff};
         off += (long long)t.h * t.w;
+        foff += feat_block_f4(t.h, t.w, CP);
         if (t.h > pf.maxh) pf.maxh = t.h;
     }
-    const int CP = (S.C + 3) & ~3;
-    if ((double)off * CP * 4.0 > 32.0 * 1024 * 1024 * 1024) { pf = TileState::PreFeat(); return OBIA_OK; }   // too big to hold: per-batch features
+    if ((double)foff * 16.0 > 32.0 * 1024 * 1024 * 1024) { pf = TileState::PreFeat(); return OBIA_OK; }   // too big to hold: per-batch features
     Arena &A = ctx->arena;
     const size_t ntot = NP * (size_t)S.C * 2 + 2 * NP;
     pf.d_windows = A.get<SrcWindow>(NP);
     pf.d_keys = A.get<unsigned>(ntot);
-    pf.d_feat = A.get<float>((size_t)off * CP);
+    pf.d_feat = A.get<float>(4 * (size_t)foff);
     if (!pf.d_windows || !pf.d_keys || !pf.d_feat) return OBIA_E_NOMEM;
     pf.host.resize(ntot);
     return OBIA_OK;
