@@ -67,7 +67,7 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #define LEAN_WAVES 8
 #endif
 #ifndef ASSIGN_WAVES
-#define ASSIGN_WAVES 6
+#define ASSIGN_WAVES 7
 #endif
 #ifndef OBIA_XCD_GROUP
 #define OBIA_XCD_GROUP 2
@@ -288,7 +288,7 @@ __device__ __forceinline__ void slic_assign_body(
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
-    int *__restrict__ orphan_flag) {
+    int *__restrict__ orphan_flag, int tiles_per_prob) {
     // colours are folded by every sweep that runs this body without LEAN (the colour sweeps and the last pre-pass sweep)
     // and by none that runs it with LEAN: a compile-time constant either way
     constexpr int accum_color = LEAN ? 0 : 1;
@@ -310,7 +310,9 @@ __device__ __forceinline__ void slic_assign_body(
     if (gtile >= total_tiles_all) return;
     STAMP_DECL
     constexpr int RS = CENT_REC + CP;
-    const int prob_i = tile_prob[gtile];
+    // (batches of equally sized problems -- the tiler's -- need no table look-up in front of the descriptor load: one
+    // dependent scalar round trip less at the head of every workgroup)
+    const int prob_i = tiles_per_prob > 0 ? gtile / tiles_per_prob : tile_prob[gtile];
     const SlicProblem P = probs[prob_i];
     const int tile = gtile - P.tile_off;
     constexpr int AQ = LEAN ? 1 : CP + 1;       // qwords of an LDS accumulator: colours (not in the lean kernel), then one packed word
@@ -509,9 +511,13 @@ __device__ __forceinline__ void slic_assign_body(
         if (fx0 >= P.W) break;   // wave-uniform
         // values derived from the lane's rows are the same in all four footprints; hoisted out of this loop they would sit in
         // ~25 registers for the whole kernel (and spill): opaque copies keep them one or two instructions away instead
-        int yb_i = yb, lane_i = lane;
-        unsigned lrow_i = lrow;
-        asm volatile("" : "+v"(yb_i), "+v"(lrow_i), "+v"(lane_i));
+        // (rebuilt from the thread index, the one vector register that is live anyway: kept across the loop, lane, yb and lrow
+        // would hold three registers for the whole kernel)
+        int tid_o = threadIdx.x;
+        asm volatile("" : "+v"(tid_o));
+        const int lane_i = tid_o & 63;
+        const int yb_i = fy0 + PPT * (lane_i >> 4);
+        const unsigned lrow_i = (unsigned)(PPT * (lane_i >> 4)) * (unsigned)P.W + (unsigned)(lane_i & 15);
         const int fx1 = min(fx0 + FB, P.W);
         const int x = fx0 + (lane_i & 15);
         const float fx = (float)x;
@@ -882,10 +888,10 @@ __device__ __forceinline__ void slic_assign_body(
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
-        int *__restrict__ orphan_flag
+        int *__restrict__ orphan_flag, int tiles_per_prob
 #define OBIA_ASSIGN_ARGS                                                                                               \
     probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
@@ -944,18 +950,20 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     constexpr int XGH = OBIA_XCD_GROUP;
     dim3 grid(8 * XGH * (unsigned)(((int)b.total_tiles_all + 8 * XGH - 1) / (8 * XGH)));   // whole groups of 8 XCDs x XG tiles (see slic_assign_body)
     const int RQ = acc_record_qwords(CP);
+    int tpp = b.probs.empty() ? 0 : b.probs[0].tiles_x * b.probs[0].tiles_y;   // tiles per problem if all problems agree, else 0
+    for (auto &P : b.probs) if (P.tiles_x * P.tiles_y != tpp) tpp = 0;
 #define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
-                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag)
+                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
                        b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
                        b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
-                       (int)b.total_tiles_all, orphan_flag)
+                       (int)b.total_tiles_all, orphan_flag, tpp)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
         if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \
