@@ -41,9 +41,9 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.slic_zero = p->slic_zero != 0;
     b.total_pix = (long long)H * W;
     SlicProblem P{};
-    P.H = H; P.W = W; P.pix_off = 0; P.feat_off = 0; P.XB = feat_xb(W);
+    P.H = H; P.W = W; P.pix_off = 0; P.feat_off = 0; P.XB = feat_xb(W); P.fb_off = 0;
     b.probs.assign(1, P);
-    b.windows.assign(1, SrcWindow{0, 0, H, W, 0, 0});
+    b.windows.assign(1, SrcWindow{0, 0, H, W, 0, 0, 0});
     b.d_windows = A.get<SrcWindow>(1);
     b.total_feat_f4 = feat_block_f4(H, W, b.CP);
     b.d_feat = A.get<float>(4 * (size_t)b.total_feat_f4);
@@ -53,6 +53,11 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.d_mask = const_cast<uint8_t *>(mask);
     const int to_lab = (C == 3 && p->convert2lab != 0) ? 1 : 0;
     const float ratio = (float)(1.0 / p->compactness);   // `image * ratio`: float32 array times Python float
+    b.col_lb = slic_use_colour_bound(ratio) && !b.slic_zero && !b.exit_on_fixed_point;
+    if (b.col_lb) {
+        b.d_fbox = A.get<float>((size_t)feat_boxes(H, W) * 2 * b.CP);
+        if (!b.d_fbox) return OBIA_E_NOMEM;
+    }
     OBIA_TRY(slic_prepare_features(ctx, b, img, H, W, p->normalize_bands, to_lab, ratio));
     std::vector<int> nseg(1, p->n_segments);
     OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, nullptr, ext));

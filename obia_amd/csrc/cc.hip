@@ -237,7 +237,7 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProbl
                                                                    const int *__restrict__ parent, const int *__restrict__ size,
                                                                    long long n, int *__restrict__ block_sums,
                                                                    int *__restrict__ counters /*[0]=n_small [1]=small_px*/) {
-    __shared__ int s_w[SCAN_NT / 64];
+    __shared__ int s_w[SCAN_NT / 64], s_ws[SCAN_NT / 64], s_wp[SCAN_NT / 64];
     const long long base = (long long)blockIdx.x * SCAN_CHUNK;
     int c = 0, nsmall = 0, spx = 0, nbig = 0;
     for (int j = 0; j < SCAN_PER; ++j) {
@@ -254,12 +254,18 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProbl
         c += __shfl_xor(c, off); nsmall += __shfl_xor(nsmall, off); spx += __shfl_xor(spx, off); nbig += __shfl_xor(nbig, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        s_w[threadIdx.x >> 6] = c;
-        if (nsmall) { atomicAdd(&counters[0], nsmall); atomicAdd(&counters[1], spx); }
+        s_w[threadIdx.x >> 6] = c; s_ws[threadIdx.x >> 6] = nsmall; s_wp[threadIdx.x >> 6] = spx;
         if (nbig) atomicAdd(&counters[6], nbig);
     }
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    // three sums per block, scanned by cc_rank_scan_kernel: survivors | small components | pixels of small components.  (Small
+    // components used to take their list slot and queue range with two global atomics EACH on two words: with the fragmented
+    // label maps of a low compactness -- millions of small components -- that was 24 ms of a 95-ms step.)
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        block_sums[gridDim.x + blockIdx.x] = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+        block_sums[2 * gridDim.x + blockIdx.x] = s_wp[0] + s_wp[1] + s_wp[2] + s_wp[3];
+    }
 }
 
 // ---- components that reach max_size -----------------------------------------------------------------------------------
@@ -340,24 +346,29 @@ __global__ __launch_bounds__(64) void cc_split_kernel(const CcProblem *__restric
 }
 
 // exclusive scan of block_sums in place, single workgroup; total -> counters[2]
-__global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ block_sums, int nb, int *__restrict__ counters) {
+__global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ block_sums_all, int nb, int *__restrict__ counters) {
     __shared__ int s_part[1024];
     const int tid = threadIdx.x;
     const int per = (nb + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, nb);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += block_sums[i];
-    s_part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (tid >= off) ? s_part[tid - off] : 0;
+    // segment 0: survivors -> counters[2]; 1: small components -> counters[0]; 2: their pixels -> counters[1]
+    for (int seg = 0; seg < 3; ++seg) {
+        int *block_sums = block_sums_all + (size_t)seg * nb;
+        int s = 0;
+        for (int i = lo; i < hi; ++i) s += block_sums[i];
+        s_part[tid] = s;
         __syncthreads();
-        s_part[tid] += v;
+        for (int off = 1; off < 1024; off <<= 1) {
+            int v = (tid >= off) ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        int run = s_part[tid] - s;
+        for (int i = lo; i < hi; ++i) { const int v = block_sums[i]; block_sums[i] = run; run += v; }
+        if (tid == 1023) counters[seg == 0 ? 2 : seg - 1] = s_part[1023];
         __syncthreads();
     }
-    int run = s_part[tid] - s;
-    for (int i = lo; i < hi; ++i) { const int v = block_sums[i]; block_sums[i] = run; run += v; }
-    if (tid == 1023) counters[2] = s_part[1023];
 }
 
 // newlab[root] = rank (>= 0) for survivors, -(index+2) for small components (collected in small_list)
@@ -365,12 +376,17 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
                                                                 const int *__restrict__ parent, const int *__restrict__ size,
                                                                 long long n, const int *__restrict__ block_sums,
                                                                 int *__restrict__ newlab, int *__restrict__ small_list,
-                                                                int *__restrict__ small_qoff, int *__restrict__ counters /*[3]=list cursor [4]=queue cursor*/) {
-    __shared__ int s_w[SCAN_NT / 64];
-    __shared__ int s_run;
+                                                                int *__restrict__ small_qoff, int *__restrict__ counters) {
+    (void)counters;
+    __shared__ int s_w[SCAN_NT / 64], s_ws[SCAN_NT / 64], s_wp[SCAN_NT / 64];
+    __shared__ int s_run, s_srun, s_prun;   // next survivor label, next slot of the small list, next queue offset
     const long long base = (long long)blockIdx.x * SCAN_CHUNK;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_run = block_sums[blockIdx.x];
+    if (threadIdx.x == 0) {
+        s_run = block_sums[blockIdx.x];
+        s_srun = block_sums[gridDim.x + blockIdx.x];
+        s_prun = block_sums[2 * gridDim.x + blockIdx.x];
+    }
     __syncthreads();
     for (int j = 0; j < SCAN_PER; ++j) {
         const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
@@ -382,21 +398,29 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
             flag = sz >= probs[find_prob(probs, nprob, i)].min_size;
             small = !flag;
         }
-        const unsigned long long bal = __ballot(flag);
-        if (lane == 0) s_w[wv] = __popcll(bal);
+        const unsigned long long bal = __ballot(flag), sbal = __ballot(small);
+        // pixels of the small components in front of this lane inside the wave (inclusive scan by shuffles, then exclusive)
+        int pin = small ? sz : 0;
+        if (sbal) {   // wave-uniform
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pin, off); if (lane >= off) pin += t; }
+        }
+        if (lane == 63) s_wp[wv] = pin;
+        if (lane == 0) { s_w[wv] = __popcll(bal); s_ws[wv] = __popcll(sbal); }
         __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wv; ++w) before += s_w[w];
+        int before = 0, sbefore = 0, pbefore = 0;
+        for (int w = 0; w < wv; ++w) { before += s_w[w]; sbefore += s_ws[w]; pbefore += s_wp[w]; }
         const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const int stotal = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3], ptotal = s_wp[0] + s_wp[1] + s_wp[2] + s_wp[3];
         if (flag) newlab[i] = s_run + before + __popcll(bal & ((1ull << lane) - 1ull));
-        if (small) {
-            const int idx = atomicAdd(&counters[3], 1);
+        if (small) {   // slots and queue ranges in raster order of the roots: no atomics
+            const int idx = s_srun + sbefore + __popcll(sbal & ((1ull << lane) - 1ull));
             small_list[idx] = (int)i;
-            small_qoff[idx] = atomicAdd(&counters[4], sz);
+            small_qoff[idx] = s_prun + pbefore + pin - sz;
             newlab[i] = -(idx + 2);
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_run += total;
+        if (threadIdx.x == 0) { s_run += total; s_srun += stotal; s_prun += ptotal; }
         __syncthreads();
     }
 }
@@ -519,7 +543,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     CcProblem *d_probs = A.get<CcProblem>(np);
     int *parent = A.get<int>(n), *size = A.get<int>(n), *newlab = A.get<int>(n);
     const int nb = cdiv(n, SCAN_CHUNK);
-    int *block_sums = A.get<int>(nb);
+    int *block_sums = A.get<int>(3 * (size_t)nb);   // survivors | small components | their pixels (cc_rank_blocksum_kernel)
     int *counters = A.get<int>(8);
     if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
     OBIA_HIP_TRY(hipMemcpyAsync(d_probs, probs.data(), sizeof(CcProblem) * np, hipMemcpyHostToDevice, ctx->stream));

@@ -276,7 +276,7 @@ static int quickshift_dev(obia_ctx *ctx, const float *img, int H, int W, int C, 
     SlicProblem P{}; P.H = H; P.W = W;
     b.probs.assign(1, P);
     b.feat_planes = false;   // pixel-major features: qs_prepare_kernel reads them per pixel
-    b.windows.assign(1, SrcWindow{0, 0, H, W, 0, 0});
+    b.windows.assign(1, SrcWindow{0, 0, H, W, 0, 0, 0});
     b.d_windows = A.get<SrcWindow>(1);
     b.d_feat = A.get<float>((size_t)n * b.CP);
     double *d_img = A.get<double>((size_t)n * C);

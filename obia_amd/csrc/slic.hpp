@@ -20,6 +20,7 @@ struct SlicProblem {
     long long feat_off;  // first float4 of this problem in the feature planes (see feat_block_f4)
     int XB;              // 16-column blocks per row of the feature planes: ceil(W / 16)
     int n_valid;         // valid (unmasked) pixels
+    long long fb_off;    // first record of this problem in the footprint colour boxes (SlicBatch::d_fbox)
 };
 
 // Source window of a problem inside the caller's raster (feature preparation).
@@ -27,7 +28,9 @@ struct SrcWindow {
     int y0, x0, h, w;
     long long pix_off;   // pixel-major feature layout (quickshift): first pixel
     long long feat_off;  // quad-row plane layout (SLIC): first float4
+    long long fb_off;    // first footprint colour box (see feat_boxes)
 };
+
 
 // Feature layout of the SLIC sweeps ("quad-row blocks").  Rows are grouped in fours, columns in sixteens; the unit is one
 // float4 = ONE channel of the four pixels (4q .. 4q+3, x):
@@ -39,6 +42,12 @@ struct SrcWindow {
 // one contiguous block.  Rows past H inside the last quad and columns past W inside the last block hold zeros.
 inline int feat_xb(int w) { return (w + 15) >> 4; }
 inline long long feat_block_f4(int h, int w, int CP) { return (long long)((h + 3) / 4) * feat_xb(w) * CP * 16; }
+
+// Footprint colour boxes (low compactness only, SlicBatch::col_lb): for every 16 x 16 footprint of the sweep -- quad rows
+// 4f .. 4f+3 of one 16-column block -- the per-channel minimum and maximum of its features, 2 * CP floats {lo[CP], hi[CP]}.
+// A candidate's colour distance to the box is a lower bound of its colour term for every pixel of the footprint: when the
+// colour term decides (compactness below ~1) the spatial bound alone visits 13 candidates per footprint, the sum 7.
+inline long long feat_boxes(int h, int w) { return (long long)(((h + 3) / 4 + 3) / 4) * feat_xb(w); }
 
 // regular_grid((1,H,W), n) of scikit-image (util/_regular_grid.py:61-83): start/step per axis,
 // step 0 == slice(None).
@@ -65,6 +74,8 @@ struct SlicBatch {
     // device arrays (arena)
     SlicProblem *d_probs = nullptr;
     SrcWindow *d_windows = nullptr;
+    float *d_fbox = nullptr;           // footprint colour boxes (feat_boxes), or null
+    bool col_lb = false;               // the sweeps add the colour-box bound to the spatial one (see slic_use_colour_bound)
     float *d_feat = nullptr;           // quad-row planes, 4 * total_feat_f4 floats (pixel-major [total_pix][CP] when !feat_planes)
     bool feat_planes = true;           // false: pixel-major features (quickshift reads them per pixel)
     long long total_feat_f4 = 0;       // float4 elements of d_feat (plane layout)
@@ -94,6 +105,11 @@ int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *non
                          std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
                           int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
+// Colour boxes of every footprint of `np` windows whose features lie in d_feat (plane layout): launch only.
+void slic_feature_boxes_launch(hipStream_t stream, int CP, int np, const SrcWindow *d_windows, long long max_boxes, const float *d_feat,
+                               float *d_fbox);
+// Does a batch with this image ratio (1 / compactness) use the colour-box bound?  (OBIA_COLOUR_BOUND=0/1 overrides.)
+bool slic_use_colour_bound(float ratio);
 
 // Seeds (grid or masked grid), fills K / steps / bins in b.probs, uploads descriptors.
 // n_segments[p] = requested segments of problem p.

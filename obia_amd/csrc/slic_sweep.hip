@@ -67,7 +67,7 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #define LEAN_WAVES 8
 #endif
 #ifndef ASSIGN_WAVES
-#define ASSIGN_WAVES 7
+#define ASSIGN_WAVES 6
 #endif
 #ifndef OBIA_XCD_GROUP
 #define OBIA_XCD_GROUP 2
@@ -280,7 +280,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 // K2: the sweep.  grid = (max tiles per problem, nprob).
 // LEAN: a spatial-only pre-pass sweep that folds no colours (nine of the ten pre-pass sweeps): no feature registers, no
 // colour scratch in LDS -- the same code with those parts compiled out, launched at a higher occupancy.
-template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN>
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN, bool COLLB>
 __device__ __forceinline__ void slic_assign_body(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
@@ -288,7 +288,11 @@ __device__ __forceinline__ void slic_assign_body(
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
-    int *__restrict__ orphan_flag, int tiles_per_prob) {
+    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox) {
+    // COLLB (low compactness): the scoring adds a lower bound of the COLOUR term to the spatial one -- the distance of the
+    // candidate's colour to the box of the footprint's features (slic.hpp: feat_boxes) -- and the visits drop from 13 to 7 per
+    // footprint at compactness 0.25.  Valid because every step is monotone: |f - c| >= max(lo - c, c - hi, 0) per channel for
+    // every pixel of the footprint, products of non-negatives and the sequential sums keep the order under rounding.
     // colours are folded by every sweep that runs this body without LEAN (the colour sweeps and the last pre-pass sweep)
     // and by none that runs it with LEAN: a compile-time constant either way
     constexpr int accum_color = LEAN ? 0 : 1;
@@ -325,6 +329,7 @@ __device__ __forceinline__ void slic_assign_body(
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
     // slot = where staging happened to put a candidate; rank = its position in ascending k (the reference's tie rule, lowest k
     // wins, becomes a comparison of ranks: the rank rides in the low word of the pixel keys and indexes the accumulators)
+    __shared__ __attribute__((aligned(16))) float s_col[COLLB ? MAXC : 1][COLLB ? CP : 4];   // COLLB: colours of the staged candidates (scoring)
     __shared__ __attribute__((aligned(16))) int s_k[MAXC];   // slot -> k
     __shared__ int s_rank[MAXC];                             // slot -> rank
     __shared__ int s_kr[MAXC];                               // rank -> k
@@ -459,6 +464,11 @@ __device__ __forceinline__ void slic_assign_body(
             // time by the scalar unit)
             const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
             const float4 r0 = src[0], r1 = src[1];
+            float4 rcol[CP / 4];
+            if (COLLB) {
+#pragma unroll
+                for (int q = 0; q < CP / 4; ++q) rcol[q] = src[2 + q];
+            }
             const int nxt = next[cur];
             const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
             const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
@@ -468,6 +478,10 @@ __device__ __forceinline__ void slic_assign_body(
                     float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
                     dh[0] = r0; dh[1] = r1;
                     s_k[slot] = cur;
+                    if (COLLB) {
+#pragma unroll
+                        for (int q = 0; q < CP / 4; ++q) *reinterpret_cast<float4 *>(&s_col[slot][4 * q]) = rcol[q];
+                    }
                 }
             }
             cur = nxt;
@@ -537,11 +551,23 @@ __device__ __forceinline__ void slic_assign_body(
         // the wave, and the wave minimum names its slot without a ballot.
         unsigned key[2];
         int kkv[2];   // global centroid index of the lane's candidate
+        float clbv[COLLB ? 2 : 1];   // COLLB: its colour-box bound
+        float blo[COLLB ? CP : 1], bhi[COLLB ? CP : 1];
+        if (COLLB) {   // the box of this footprint: wave-uniform address, scalar loads
+            const float4 *bx = reinterpret_cast<const float4 *>(fbox) + (P.fb_off + (long long)(fy0_o >> 4) * P.XB + (fx0 >> 4)) * (2 * CP / 4);
+#pragma unroll
+            for (int q = 0; q < CP / 4; ++q) {
+                const float4 l = bx[q], h = bx[CP / 4 + q];
+                blo[4 * q] = l.x; blo[4 * q + 1] = l.y; blo[4 * q + 2] = l.z; blo[4 * q + 3] = l.w;
+                bhi[4 * q] = h.x; bhi[4 * q + 1] = h.y; bhi[4 * q + 2] = h.z; bhi[4 * q + 3] = h.w;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int c = 64 * r + lane_i;
             key[r] = 0xffffffffu;
             kkv[r] = 0;
+            if (COLLB) clbv[r] = 0.0f;
             // (the float images of the footprint's edges are rebuilt here from scalar registers: kept across the
             // footprint loop they cost vector registers the visit loop needs)
             int fy0 = fy0_o, fy1 = fy1_o;
@@ -557,8 +583,24 @@ __device__ __forceinline__ void slic_assign_body(
                     const float ry = (cy < (float)fy0) ? (float)fy0 : ((cy > (float)(fy1 - 1)) ? (float)(fy1 - 1) : cy);
                     const float rx = (cx < (float)fx0) ? (float)fx0 : ((cx > (float)(fx1 - 1)) ? (float)(fx1 - 1) : cx);
                     const float tyv = cy - ry, txv = cx - rx;
-                    const float lb = (tyv * tyv + txv * txv) * w;
-                    key[r] = (__float_as_uint(lb) & ~127u) | (unsigned)s_rank[c];      // lb >= 0 and finite: never 0xffffffff
+                    float lb = (tyv * tyv + txv * txv) * w;
+                    if (COLLB) {
+                        // dc = sum over channels, in channel order, of (f - c)^2 >= the same sum of max(lo - c, c - hi, 0)^2
+                        float cl = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < CP / 4; ++q) {
+                            const float4 cc = *reinterpret_cast<const float4 *>(&s_col[c][4 * q]);
+                            const float cv[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = fmaxf(fmaxf(blo[4 * q + e] - cv[e], cv[e] - bhi[4 * q + e]), 0.0f);
+                                cl += t * t;
+                            }
+                        }
+                        clbv[r] = cl;
+                        lb += cl;
+                    }
+                    key[r] = (__float_as_uint(lb) & ~127u) | (unsigned)s_rank[c];      // lb >= 0, never NaN: below 0xffffffff
                 }
             }
         }
@@ -591,6 +633,12 @@ __device__ __forceinline__ void slic_assign_body(
             const int kk = m0 ? __builtin_amdgcn_readlane(kkv[0], (int)__builtin_ctzll(m0)) : __builtin_amdgcn_readlane(kkv[1], (int)__builtin_ctzll(m1));
             key[0] = (key[0] == mn) ? 0xffffffffu : key[0];
             key[1] = (key[1] == mn) ? 0xffffffffu : key[1];
+            float clb = 0.0f;   // COLLB: the candidate's colour-box bound (uniform)
+            if (COLLB) {
+                const int sl = m0 ? (int)__builtin_ctzll(m0) : (int)__builtin_ctzll(m1);
+                clb = m0 ? __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clbv[0]), sl))
+                         : __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clbv[COLLB ? 1 : 0]), sl));
+            }
             const float4 *__restrict__ crec = reinterpret_cast<const float4 *>(cent + (size_t)kk * RS);
             const float4 h0 = crec[0], h1 = crec[1];
             // the next candidate, under the latency of the loads
@@ -626,7 +674,9 @@ __device__ __forceinline__ void slic_assign_body(
             }
             // colour >= 0 and float add is monotone, so d >= spatial: a candidate whose spatial part already exceeds the best
             // distance of a pixel cannot win it (equality could still tie on k): no such pixel in the wave -> no colours
-            const bool anylive = !(dv[0] > BK_D(0)) || !(dv[1] > BK_D(1)) || !(dv[2] > BK_D(2)) || !(dv[3] > BK_D(3));
+            // (COLLB: d = spatial + dc >= spatial + colour bound, both sums rounded the same way)
+            const bool anylive = COLLB ? (!(dv[0] + clb > BK_D(0)) || !(dv[1] + clb > BK_D(1)) || !(dv[2] + clb > BK_D(2)) || !(dv[3] + clb > BK_D(3)))
+                                       : (!(dv[0] > BK_D(0)) || !(dv[1] > BK_D(1)) || !(dv[2] > BK_D(2)) || !(dv[3] > BK_D(3)));
             STAMP_COUNT(1, 1)   // visits
             STAMP(9)   // visit: spatial + live test
             if (!__ballot(anylive)) continue;
@@ -888,21 +938,27 @@ __device__ __forceinline__ void slic_assign_body(
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
-        int *__restrict__ orphan_flag, int tiles_per_prob
+        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox
 #define OBIA_ASSIGN_ARGS                                                                                               \
     probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ASSIGN_WAVES, ASSIGN_WAVES))) void slic_assign_kernel(OBIA_ASSIGN_PARAMS) {
-    slic_assign_body<CP, MASKED, IGNORE_COLOR, FIXPT, SLICZERO, false>(OBIA_ASSIGN_ARGS);
+    slic_assign_body<CP, MASKED, IGNORE_COLOR, FIXPT, SLICZERO, false, false>(OBIA_ASSIGN_ARGS);
+}
+
+// the colour sweeps at low compactness: with the colour-box bound (one more LDS table, a few more registers)
+template <int CP, bool MASKED>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void slic_assign_collb_kernel(OBIA_ASSIGN_PARAMS) {
+    slic_assign_body<CP, MASKED, false, false, false, false, true>(OBIA_ASSIGN_ARGS);
 }
 
 // the pre-pass sweeps that fold no colours: no feature registers, 4 KB of LDS
 template <int CP, bool MASKED, bool FIXPT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LEAN_WAVES, LEAN_WAVES))) void slic_prepass_kernel(OBIA_ASSIGN_PARAMS) {
-    slic_assign_body<CP, MASKED, true, FIXPT, false, true>(OBIA_ASSIGN_ARGS);
+    slic_assign_body<CP, MASKED, true, FIXPT, false, true, false>(OBIA_ASSIGN_ARGS);
 }
 
 #ifdef OBIA_STAMP
@@ -956,19 +1012,25 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
-                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp)
+                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
+#define LAUNCH_COLLB_(M)                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, ctx->stream, b.d_probs,   \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
+                       store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
+                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
                        b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
                        b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
-                       (int)b.total_tiles_all, orphan_flag, tpp)
+                       (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
         if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \
         else if (b.slic_zero && !(I)) LAUNCH_ASSIGN_(M, false, false, true);                                         \
         else if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true, false);                                                    \
+        else if (b.col_lb && b.d_fbox && !(I)) LAUNCH_COLLB_(M);                                                     \
         else LAUNCH_ASSIGN_(M, I, false, false);                                                                     \
     } while (0)
     if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
@@ -976,6 +1038,7 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
 #undef LAUNCH_ASSIGN
 #undef LAUNCH_ASSIGN_
 #undef LAUNCH_LEAN_
+#undef LAUNCH_COLLB_
 }
 
 __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {

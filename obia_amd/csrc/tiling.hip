@@ -263,6 +263,7 @@ struct TileState {
         std::vector<SrcWindow> windows;
         std::vector<unsigned> host;      // keys | nonfinite | max|feature| of all windows
         float *d_feat = nullptr;
+        float *d_fbox = nullptr;         // footprint colour boxes of the same windows (low compactness only)
         SrcWindow *d_windows = nullptr;
         unsigned *d_keys = nullptr;
         int maxh = 1;
@@ -294,21 +295,23 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.max_iter = S.sp.max_num_iter;
     b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
     b.slic_zero = S.sp.slic_zero != 0;
-    long long off = 0, foff = 0, maxpix = 1;
+    long long off = 0, foff = 0, boff = 0, maxpix = 1;
     b.probs.resize(np);
     b.windows.resize(np);
     for (int p = 0; p < np; ++p) {
         wins[p].pix_off = off;
         SlicProblem P{};
-        P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off; P.feat_off = foff; P.XB = feat_xb(wins[p].w);
+        P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off; P.feat_off = foff; P.XB = feat_xb(wins[p].w); P.fb_off = boff;
         b.probs[p] = P;
-        b.windows[p] = SrcWindow{wins[p].y0, wins[p].x0, wins[p].h, wins[p].w, off, foff};
+        b.windows[p] = SrcWindow{wins[p].y0, wins[p].x0, wins[p].h, wins[p].w, off, foff, boff};
         const long long n = (long long)wins[p].h * wins[p].w;
         if (n > maxpix) maxpix = n;
         off += n;
         foff += feat_block_f4(wins[p].h, wins[p].w, b.CP);
+        boff += feat_boxes(wins[p].h, wins[p].w);
     }
     b.total_feat_f4 = foff;
+    b.col_lb = slic_use_colour_bound((float)(1.0 / S.sp.compactness)) && !b.slic_zero && !b.exit_on_fixed_point;
     if (off > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
     b.total_pix = off;
     TileWin *d_wins = A.get<TileWin>(np);
@@ -325,8 +328,13 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         // (the prefetched planes of these windows lie back to back in the same order: the batch's feat_off values, which
         // start at 0, are offsets from the first window's block)
         b.d_feat = S.pf.d_feat + 4 * (size_t)S.pf.windows[S.pf.cursor].feat_off;
+        if (b.col_lb) b.d_fbox = S.pf.d_fbox + (size_t)S.pf.windows[S.pf.cursor].fb_off * 2 * b.CP;
     } else {
         b.d_feat = A.get<float>(4 * (size_t)foff);
+        if (b.col_lb) {
+            b.d_fbox = A.get<float>((size_t)boff * 2 * b.CP);
+            if (!b.d_fbox) return OBIA_E_NOMEM;
+        }
     }
     b.d_labels = A.get<int32_t>((size_t)off);
     int32_t *d_final = A.get<int32_t>((size_t)off);
@@ -479,15 +487,16 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
         }
     const size_t NP = pf.wins.size();
     if (NP == 0) return OBIA_OK;
-    long long off = 0, foff = 0;
+    long long off = 0, foff = 0, boff = 0;
     const int CP = (S.C + 3) & ~3;
     pf.windows.resize(NP);
     for (size_t p = 0; p < NP; ++p) {
         const TileWin &t = pf.wins[p];
         if (t.y0 < 0 || t.y0 + t.h > S.H) { pf = TileState::PreFeat(); return OBIA_OK; }   // the batches report the halo error
-        pf.windows[p] = SrcWindow{t.y0, t.x0, t.h, t.w, off, foff};
+        pf.windows[p] = SrcWindow{t.y0, t.x0, t.h, t.w, off, foff, boff};
         off += (long long)t.h * t.w;
         foff += feat_block_f4(t.h, t.w, CP);
+        boff += feat_boxes(t.h, t.w);
         if (t.h > pf.maxh) pf.maxh = t.h;
     }
     if ((double)foff * 16.0 > 32.0 * 1024 * 1024 * 1024) { pf = TileState::PreFeat(); return OBIA_OK; }   // too big to hold: per-batch features
@@ -497,6 +506,10 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
     pf.d_keys = A.get<unsigned>(ntot);
     pf.d_feat = A.get<float>(4 * (size_t)foff);
     if (!pf.d_windows || !pf.d_keys || !pf.d_feat) return OBIA_E_NOMEM;
+    if (slic_use_colour_bound((float)(1.0 / S.sp.compactness)) && !S.sp.slic_zero && !S.sp.exit_on_fixed_point) {
+        pf.d_fbox = A.get<float>((size_t)boff * 2 * CP);
+        if (!pf.d_fbox) return OBIA_E_NOMEM;
+    }
     pf.host.resize(ntot);
     return OBIA_OK;
 }
@@ -512,6 +525,11 @@ static int prefetch_white_launch(obia_ctx *ctx, TileState &S) {
     const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
     OBIA_TRY(slic_features_launch(ctx->stream, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
                                   (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys));
+    if (pf.d_fbox) {
+        long long mb = 1;
+        for (auto &w : pf.windows) mb = std::max(mb, feat_boxes(w.h, w.w));
+        slic_feature_boxes_launch(ctx->stream, CP, (int)NP, pf.d_windows, mb, pf.d_feat, pf.d_fbox);
+    }
     return OBIA_OK;
 }
 

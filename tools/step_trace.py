@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 img = synth_raster(S, S, 8, 0, dev)
 mask = torch.ones((S, S), dtype=torch.uint8, device=dev)
 ctx = _lib.Context(0)
-kw = dict(tile_size=2048, buffer=64, crown_radius=5, pixel_size=(0.5, 0.5), compactness=10.0, ctx=ctx)
+kw = dict(tile_size=2048, buffer=64, crown_radius=5, pixel_size=(0.5, 0.5), compactness=float(os.environ.get("OBIA_TRACE_COMPACTNESS", "10")), ctx=ctx)
 for _ in range(int(os.environ.get("OBIA_TRACE_STEPS", "2"))):
     lab, n = create_tiled_segments(img, input_mask=mask, **kw)
     st = zonal_stats(img, lab, n_labels=n, ctx=ctx)

@@ -19,7 +19,7 @@ n = round(H * W / 324.0)
 iters = int(os.environ.get("TL_ITERS", "4"))   # the last sweep of a call does not accumulate: look at the one before by running iters+... no: max_num_iter
 mask = torch.ones((H, W), dtype=torch.bool, device="cuda") if os.environ.get("TL_MASK") else None
 for _ in range(2):
-    slic(img, n_segments=n, compactness=10.0, _normalize_bands=True, max_num_iter=iters, mask=mask, _stage="pre")
+    slic(img, n_segments=n, compactness=float(os.environ.get("TL_COMPACT", "10")), _normalize_bands=True, max_num_iter=iters, mask=mask, _stage="pre")
 torch.cuda.synchronize()
 NT = (H // 64) * (W // 64)
 buf = np.zeros(NT * 4 * 24, np.uint64)
