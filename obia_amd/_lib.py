@@ -159,7 +159,8 @@ class Context:
             pass
 
     def set_profiling(self, on):
-        check(load().obia_set_profiling(self._h, int(bool(on))))
+        """False / 0: off; True / 1: event pairs around every kernel class; 2: around the SLIC colour sweeps only."""
+        check(load().obia_set_profiling(self._h, int(on)))
 
     def timing(self):
         lib = load()

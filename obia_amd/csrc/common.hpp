@@ -68,7 +68,7 @@ struct obia_ctx {
     obia::Arena arena;
     void *pinned = nullptr;          // small pinned host staging buffer for scalar read-backs
     size_t pinned_bytes = 0;
-    bool profiling = false;
+    int profiling = 0;               // 0 off, 1 every span, 2 only the colour sweeps (obia_set_profiling)
     obia::Timing timing;
     // event pairs recorded around kernels of interest; resolved (one sync) at the end of the call
     struct Span { int kind; hipEvent_t a, b; };

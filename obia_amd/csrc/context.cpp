@@ -102,7 +102,7 @@ static hipEvent_t get_event(obia_ctx *ctx) {
     return ctx->event_pool[ctx->events_used++];
 }
 
-ScopedSpan::ScopedSpan(obia_ctx *c, int kind) : ctx(c), on(c->profiling), idx(0) {
+ScopedSpan::ScopedSpan(obia_ctx *c, int kind) : ctx(c), on(c->profiling == 1 || (c->profiling == 2 && kind == T_ASSIGN)), idx(0) {
     if (!on) return;
     obia_ctx::Span s{kind, get_event(ctx), get_event(ctx)};
     (void)hipEventRecord(s.a, ctx->stream);
@@ -230,7 +230,7 @@ void obia_slic_default_params(obia_slic_params *p) {
 
 int obia_set_profiling(obia_ctx *ctx, int enabled) {
     if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
-    ctx->profiling = enabled != 0;
+    ctx->profiling = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);
     return OBIA_OK;
 }
 

@@ -11,17 +11,19 @@
 //              rule; the sums are exact integers (coordinates) / 64-bit fixed point (colours).
 //
 // Kernel shape (gfx950): one 256-thread workgroup per 64x64 pixel tile (SWEEP_TW x SWEEP_TH, slic.hpp).
-//   1. the workgroup stages into LDS the header of every centroid whose window intersects the tile (lanes walk
-//      the per-bin linked lists built by slic_prep_kernel) and sorts the slots by centroid index k, so that
-//      "lower slot" == "lower k" and the reference's tie rule becomes a comparison of slot numbers;
-//   2. each wave walks four 16x16 footprints (one 16-row band of the tile); a lane owns a 1x4 vertical strip.
-//      Lanes first score the staged candidates in parallel (one candidate per lane): window-intersects-footprint
-//      and a lower bound `lb` of the spatial term over the footprint; candidates are then visited in ascending lb
-//      and the walk stops when lb exceeds the largest current best distance in the wave (d >= spatial >= lb,
-//      float add/mul are monotone, so nothing that is skipped could have won or tied).  A pixel's state is ONE
-//      64-bit key  float_bits(d) << 32 | slot : distances are non-negative floats, whose bit patterns order like
-//      their values, so `new_key < key` is exactly the lexicographic (d, k) comparison of the reference -- no
-//      separate tie path, no second register for the label;
+//   1. the workgroup stages into LDS the header of every centroid whose window intersects the tile (lanes walk the per-bin
+//      linked lists built by slic_prep_kernel) and ranks the slots by centroid index k (rank table: broadcast LDS reads, no
+//      serial chain), so that the reference's tie rule (lowest k wins) becomes a comparison of ranks;
+//   2. each wave walks four 16x16 footprints (one 16-row band of the tile); a lane owns a 1x4 vertical strip = one quad row of
+//      the feature layout (slic.hpp: feat_block_f4): ONE 16-byte load per channel brings that channel of its four pixels.
+//      Lanes first score the staged candidates in parallel (one candidate per lane): window-intersects-footprint and a lower
+//      bound `lb` of the spatial term over the footprint (plus, at low compactness, a lower bound of the colour term from the
+//      footprint's colour box); candidates are then visited in ascending lb and the walk stops when lb exceeds the largest
+//      current best distance in the wave (d >= lb, float add/mul are monotone, so nothing that is skipped could have won or
+//      tied).  A visit reads the candidate's record through the scalar unit (SGPR operands, no vector / LDS instruction) and
+//      evaluates the lane's four pixels as two packed-f32 pairs.  A pixel's state is ONE 64-bit key
+//      float_bits(d) << 32 | rank : distances are non-negative floats, whose bit patterns order like their values, so
+//      `new_key < key` is exactly the lexicographic (d, k) comparison of the reference -- no separate tie path;
 //   3. the centroid update is fused: every feature is converted once to 32-bit fixed point (a power-of-two scale:
 //      exact for all but the smallest 1/64 of the value range), per-lane run sums are plain int32, they are
 //      transposed through a conflict-free LDS scratch so that 8 lanes x CP fields fold the wave's 64 strips
@@ -610,10 +612,11 @@ __device__ __forceinline__ void slic_assign_body(
         // ---- visit candidates in ascending lb until lb exceeds every lane's current best ---------------------------
         // a lane's largest current best distance (+inf while one of its valid pixels is unassigned, 0 when it has no
         // valid pixel): the walk stops when lb exceeds it in every lane -- one compare and a ballot, no wave reduction.
-        // The kernel is bound by the dependent chain of a single wave, not by instruction issue (a wave alone on its SIMD
-        // needs 2/3 of the time it needs with five neighbours), so an iteration is ONE straight-line block as far as
-        // possible: the record is requested from LDS first, the wave minimum that names the NEXT candidate is computed
-        // under that latency, the window test is applied by selects, and the two row pairs run as two interleaved chains.
+        // The kernel is bound by VALU issue first and by the dependent chain of a single wave second (a wave alone on its
+        // SIMD still needs 2/3 of the time it needs with five neighbours), so an iteration is one straight-line block with
+        // as few vector instructions as possible: the record is requested by the scalar unit first, the wave minimum that
+        // names the NEXT candidate is computed under that latency, the per-pixel window test runs only when the window
+        // does not cover the footprint, and the two row pairs run as two interleaved packed chains.
         float mybest = fmaxf(fmaxf(BK_D(0), BK_D(1)), fmaxf(BK_D(2), BK_D(3)));
 #ifdef OBIA_ABL_VISITS
         int abl_visits = 0;
