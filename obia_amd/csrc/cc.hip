@@ -546,7 +546,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *block_sums = A.get<int>(3 * (size_t)nb);   // survivors | small components | their pixels (cc_rank_blocksum_kernel)
     int *counters = A.get<int>(8);
     if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
-    OBIA_HIP_TRY(hipMemcpyAsync(d_probs, probs.data(), sizeof(CcProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_TRY(upload_async(ctx, d_probs, probs.data(), sizeof(CcProblem) * np));
     OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
     int gs = cdiv(n, 256 * 4);
     if (gs > 65535 * 4) gs = 65535 * 4;

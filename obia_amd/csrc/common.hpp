@@ -68,6 +68,8 @@ struct obia_ctx {
     obia::Arena arena;
     void *pinned = nullptr;          // small pinned host staging buffer for scalar read-backs
     size_t pinned_bytes = 0;
+    char *up_buf = nullptr;          // pinned ring for small host -> device tables (upload_async): no stream sync per upload
+    size_t up_bytes = 0, up_used = 0;
     int profiling = 0;               // 0 off, 1 every span, 2 only the colour sweeps (obia_set_profiling)
     obia::Timing timing;
     // event pairs recorded around kernels of interest; resolved (one sync) at the end of the call
@@ -92,6 +94,10 @@ void begin_timing(obia_ctx *ctx);
 void resolve_timing(obia_ctx *ctx);
 
 int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  // async copy + stream sync
+// Host table -> device without a stream synchronisation: the bytes are copied into a pinned ring first, so the caller's
+// (pageable, short-lived) buffer is free at once; the ring is recycled at the next read_back (everything queued before it
+// has then executed).
+int upload_async(obia_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -148,7 +148,35 @@ int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) 
     }
     OBIA_HIP_TRY(hipMemcpyAsync(ctx->pinned, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->up_used = 0;   // every upload queued so far has executed: the ring is free again
     memcpy(host_dst, ctx->pinned, bytes);
+    return OBIA_OK;
+}
+
+int upload_async(obia_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+    if (bytes == 0) return OBIA_OK;
+    constexpr size_t RING = 8u << 20;
+    if (!ctx->up_buf) {
+        void *p = nullptr;
+        OBIA_HIP_TRY(hipHostMalloc(&p, RING, hipHostMallocDefault));
+        ctx->up_buf = static_cast<char *>(p);
+        ctx->up_bytes = RING;
+        ctx->up_used = 0;
+    }
+    if (bytes > ctx->up_bytes) {   // too big for the ring: plain synchronous copy
+        OBIA_HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->up_used = 0;
+        return OBIA_OK;
+    }
+    if (ctx->up_used + bytes > ctx->up_bytes) {   // ring full: wait for what is queued, start over
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->up_used = 0;
+    }
+    char *slot = ctx->up_buf + ctx->up_used;
+    memcpy(slot, host_src, bytes);
+    OBIA_HIP_TRY(hipMemcpyAsync(dev_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->up_used += (bytes + 63) & ~(size_t)63;
     return OBIA_OK;
 }
 
@@ -199,6 +227,7 @@ void obia_destroy(obia_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->arena.release();
+    if (ctx->up_buf) (void)hipHostFree(ctx->up_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -615,7 +615,7 @@ int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid) {
     if (!b.d_probs) b.d_probs = A.get<SlicProblem>(np);
     if (!b.d_probs) return OBIA_E_NOMEM;
     if (b.masked) {
-        OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+        OBIA_TRY(upload_async(ctx, b.d_probs, b.probs.data(), sizeof(SlicProblem) * np));
         int *d_cnt = A.get<int>(np);
         if (!d_cnt) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * np, ctx->stream));
@@ -688,19 +688,18 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     SeedGrid *d_grids = A.get<SeedGrid>(np);
     if (!b.d_seed || !b.d_cent_prob || !d_grids) return OBIA_E_NOMEM;
     OBIA_HIP_TRY(hipMemsetAsync(b.d_cent_prob, 0xff, sizeof(int) * b.total_cent, ctx->stream));
-    OBIA_HIP_TRY(hipMemcpyAsync(d_grids, grids.data(), sizeof(SeedGrid) * np, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_TRY(upload_async(ctx, d_grids, grids.data(), sizeof(SeedGrid) * np));
     std::vector<int> K(np);
     if (ext) {
         std::vector<float> hs((size_t)ext->n * 2);
         for (size_t i = 0; i < hs.size(); ++i) hs[i] = (float)ext->yx[i];   // segments.astype(float32): centroids are float
         OBIA_HIP_TRY(hipMemsetAsync(b.d_cent_prob, 0, sizeof(int) * b.total_cent, ctx->stream));
-        OBIA_HIP_TRY(hipMemcpyAsync(b.d_seed, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, ctx->stream));
-        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        OBIA_TRY(upload_async(ctx, b.d_seed, hs.data(), sizeof(float) * hs.size()));
         K[0] = nvalid[0] > 0 ? ext->n : 0;
     } else if (b.masked) {
         int *d_K = A.get<int>(np);
         if (!d_K) return OBIA_E_NOMEM;
-        OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
+        OBIA_TRY(upload_async(ctx, b.d_probs, b.probs.data(), sizeof(SlicProblem) * np));
         hipLaunchKernelGGL(seed_masked_kernel, dim3(np), dim3(256), 0, ctx->stream, d_grids, b.d_probs, b.d_mask,
                            b.d_seed, b.d_cent_prob, d_K);
         OBIA_TRY(read_back(ctx, K.data(), d_K, sizeof(int) * np));
@@ -710,7 +709,6 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         for (int p = 0; p < np; ++p) { K[p] = grids[p].ny * grids[p].nx; if (K[p] > maxK) maxK = K[p]; }
         hipLaunchKernelGGL(seed_grid_kernel, dim3(cdiv(maxK, 256), np), dim3(256), 0, ctx->stream, d_grids, np,
                            b.d_seed, b.d_cent_prob);
-        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // grids/probs host vectors are pageable
     }
     // window steps, bins, tiles
     int cell_off = 0, tile_max = 0;
@@ -744,13 +742,11 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
             for (int t = 0; t < b.probs[p].tiles_x * b.probs[p].tiles_y; ++t) tp[(size_t)b.probs[p].tile_off + t] = p;
         b.d_tile_prob = A.get<int>(tp.size());
         if (!b.d_tile_prob) return OBIA_E_NOMEM;
-        OBIA_HIP_TRY(hipMemcpyAsync(b.d_tile_prob, tp.data(), sizeof(int) * tp.size(), hipMemcpyHostToDevice, ctx->stream));
-        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tp is pageable
+        OBIA_TRY(upload_async(ctx, b.d_tile_prob, tp.data(), sizeof(int) * tp.size()));   // (pinned ring: tp may go out of scope)
     }
     b.total_cells = cell_off > 0 ? cell_off : 1;
     b.total_tiles = tile_max;
-    OBIA_HIP_TRY(hipMemcpyAsync(b.d_probs, b.probs.data(), sizeof(SlicProblem) * np, hipMemcpyHostToDevice, ctx->stream));
-    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    OBIA_TRY(upload_async(ctx, b.d_probs, b.probs.data(), sizeof(SlicProblem) * np));
     const int RS = CENT_REC + b.CP;
     b.d_cent = A.get<float>((size_t)b.total_cent * RS);
     b.d_head = A.get<int>((size_t)b.total_cells * 2);

@@ -339,9 +339,8 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.d_labels = A.get<int32_t>((size_t)off);
     int32_t *d_final = A.get<int32_t>((size_t)off);
     if (!d_wins || !b.d_windows || !b.d_mask || !b.d_feat || !b.d_labels || !d_final) return OBIA_E_NOMEM;
-    OBIA_HIP_TRY(hipMemcpyAsync(d_wins, wins.data(), sizeof(TileWin) * np, hipMemcpyHostToDevice, ctx->stream));
-    OBIA_HIP_TRY(hipMemcpyAsync(b.d_windows, b.windows.data(), sizeof(SrcWindow) * np, hipMemcpyHostToDevice, ctx->stream));
-    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    OBIA_TRY(upload_async(ctx, d_wins, wins.data(), sizeof(TileWin) * np));   // (pinned ring: no stream sync per small table)
+    OBIA_TRY(upload_async(ctx, b.d_windows, b.windows.data(), sizeof(SrcWindow) * np));
     if (white) {
         OBIA_HIP_TRY(hipMemsetAsync(S.inside, 0, sizeof(unsigned) * (size_t)S.next_id, ctx->stream));
         hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
@@ -399,7 +398,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         S.next_id += n_new;
     }
     OBIA_HIP_TRY(hipGetLastError());
-    OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));   // host vectors of this batch go out of scope
+    // (no synchronisation here: every host table of the batch went through upload_async, and the arena is reused in stream order)
     A.rewind(mk);
     return OBIA_OK;
 }
@@ -521,7 +520,7 @@ static int prefetch_white_launch(obia_ctx *ctx, TileState &S) {
     ScopedSpan span(ctx, T_FEAT);
     const size_t NP = pf.wins.size();
     const int CP = (S.C + 3) & ~3;
-    OBIA_HIP_TRY(hipMemcpyAsync(pf.d_windows, pf.windows.data(), sizeof(SrcWindow) * NP, hipMemcpyHostToDevice, ctx->stream));
+    OBIA_TRY(upload_async(ctx, pf.d_windows, pf.windows.data(), sizeof(SrcWindow) * NP));
     const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
     OBIA_TRY(slic_features_launch(ctx->stream, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
                                   (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys));
