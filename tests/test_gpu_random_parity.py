@@ -4,6 +4,8 @@ thin pieces (valid pixels that no window reaches keep their previous label: the 
 labels), start_label 0 / 1, few sweeps.  Seeds are fixed: the cases are the same on every run.
 Bar: labels before connectivity differ on <= 1e-4 of the pixels (the only source is the rounding of centroid colour means: exact
 fixed point here, sequential float32 in the reference), final labels ARI >= 0.99; the cases at compactness >= 5 must be bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -41,7 +43,7 @@ def make_case(seed):
     return img, mask, kw
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OBIA_RANDOM_CASES", "40"))))   # (a longer soak: OBIA_RANDOM_CASES=400)
 def test_random_case_vs_oracle(oracle, seed):
     from obia_amd.segmentation import slic
     img, mask, kw = make_case(seed)
