@@ -101,14 +101,19 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     const int lane = threadIdx.x & 63, gl0 = lane - q;       // first lane of the group inside the wave
     const bool in_range = k < total_cent;
     const int p = in_range ? cent_prob[k] : -1;
+    // everything whose address depends on k alone is requested before the problem descriptor (which depends on cent_prob[k]) is
+    // waited for: the kernel is a chain of dependent round trips (4 -> 3), 180 launches per step of the tiler
+    const int RS = CENT_REC + CP;
+    float *rec = cent + (size_t)(in_range ? k : 0) * RS;
+    const float old_cy_l = in_range ? rec[0] : 0.0f, old_cx_l = in_range ? rec[1] : 0.0f;
+    const float oldc_l = (in_range && !first && q < CP) ? rec[CENT_REC + q] : 0.0f;
+    const unsigned long long aq_l = (in_range && !first) ? acc[(size_t)k * G + q] : 0ull;
     SlicProblem P;
     bool live = p >= 0;
     if (live) { P = probs[p]; live = (k - P.cent_off) < P.K; }
-    const int RS = CENT_REC + CP;
-    float *rec = cent + (size_t)(live ? k : 0) * RS;
     float cy = 0.0f, cx = 0.0f;
     bool moved = false;
-    const float old_cy = live ? rec[0] : 0.0f, old_cx = live ? rec[1] : 0.0f;
+    const float old_cy = live ? old_cy_l : 0.0f, old_cx = live ? old_cx_l : 0.0f;
     if (first) {
         if (live) {
             cy = seed[2 * (size_t)k];
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
         moved = true;
     } else {
         unsigned long long *a = acc + (size_t)(live ? k : 0) * G;
-        const unsigned long long aq = live ? a[q] : 0ull;
-        const float oldc = (live && q < CP) ? rec[CENT_REC + q] : 0.0f;
+        const unsigned long long aq = live ? aq_l : 0ull;
+        const float oldc = (live && q < CP) ? oldc_l : 0.0f;
         if (live) a[q] = 0ull;
         // every lane takes part in the shuffles (dead groups carry zeros).  n, sum_y and sum_x are full 64-bit words:
         // sum_y reaches 2^32 as soon as (pixels of a cluster) x (row) does -- a coarse segmentation of a big raster
