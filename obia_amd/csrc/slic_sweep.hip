@@ -455,28 +455,35 @@ __device__ __forceinline__ void slic_assign_body(
     } else if (px_counter && tile == 0 && tid == 0) {
         atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
     }
+    // ---- 1. stage the candidates of the tile: lanes walk the lists of the bins whose centroids can reach it ------------------
+    // The two dependent round trips of a lane's first list node (bin head -> record + link) touch no LDS: they are issued
+    // BEFORE the accumulators are cleared and the first barrier is waited for, so that clearing and barrier run under them.
+    auto bin_head = [&](int bi) { return head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw]; };
+    int cur = (tid < nbins) ? bin_head(tid) : -1;
     for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
     for (int i = tid; i < SWEEP_TH * SWEEP_TW / 32; i += NT) s_orph[i] = 0u;
+    if (tid < MAXC) s_k[tid] = 0x7fffffff;   // sentinel: the rank loop reads whole groups of eight entries without bound checks
     if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, rcol[CP / 4];
+#pragma unroll
+    for (int q = 0; q < CP / 4; ++q) rcol[q] = r0;
+    int nxt = -1;
+    auto load_node = [&](int c) {   // header, link (and colours for the colour-box bound) of one list node: one round trip
+        const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)c * RS);
+        r0 = src[0]; r1 = src[1];
+        if (COLLB) {
+#pragma unroll
+            for (int q = 0; q < CP / 4; ++q) rcol[q] = src[2 + q];
+        }
+        nxt = next[c];
+    };
+    if (cur >= 0) load_node(cur);
     __syncthreads();
-
-    // ---- 1. stage the candidates of the tile: lanes walk the lists of the bins whose centroids can reach it ------------------
-    // (the features of the wave's FIRST footprint are requested first: their HBM latency overlaps the dependent
-    // bin -> record loads)
+    // (the features of the wave's FIRST footprint: their HBM latency runs under the rest of the staging, the ranking and the scoring)
     if (wave_active) fetch(tx0, yb, lrow, lane, true);
     for (int bi = tid; bi < nbins; bi += NT) {
-        int cur = head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw];
+        if (bi != tid) { cur = bin_head(bi); if (cur >= 0) load_node(cur); }   // (more than 256 bins: tiny steps)
         while (cur >= 0) {
-            // one round trip per list node: the header and the link are requested together (the colours are read at visit
-            // time by the scalar unit)
-            const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)cur * RS);
-            const float4 r0 = src[0], r1 = src[1];
-            float4 rcol[CP / 4];
-            if (COLLB) {
-#pragma unroll
-                for (int q = 0; q < CP / 4; ++q) rcol[q] = src[2 + q];
-            }
-            const int nxt = next[cur];
             const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
             const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
             if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
@@ -492,6 +499,7 @@ __device__ __forceinline__ void slic_assign_body(
                 }
             }
             cur = nxt;
+            if (cur >= 0) load_node(cur);
         }
     }
     __syncthreads();
@@ -509,12 +517,10 @@ __device__ __forceinline__ void slic_assign_body(
         if (tid < nc) {
             const int myk = s_k[tid];
             int r = 0;
-            for (int i = 0; i < nc; i += 4) {
-                const int4 kq = *reinterpret_cast<const int4 *>(&s_k[i]);
-                r += (kq.x < myk) ? 1 : 0;
-                r += (i + 1 < nc && kq.y < myk) ? 1 : 0;
-                r += (i + 2 < nc && kq.z < myk) ? 1 : 0;
-                r += (i + 3 < nc && kq.w < myk) ? 1 : 0;
+#pragma unroll 1
+            for (int i = 0; i < nc; i += 8) {   // eight entries per step: two independent reads in flight (unstaged slots hold INT_MAX)
+                const int4 ka = *reinterpret_cast<const int4 *>(&s_k[i]), kb = *reinterpret_cast<const int4 *>(&s_k[i + 4]);
+                r += (ka.x < myk) + (ka.y < myk) + (ka.z < myk) + (ka.w < myk) + (kb.x < myk) + (kb.y < myk) + (kb.z < myk) + (kb.w < myk);
             }
             s_rank[tid] = r;
             s_kr[r] = myk;
