@@ -386,6 +386,7 @@ __device__ __forceinline__ void slic_assign_body(
     // fold, the next scoring and the first selection run under the memory latency.  `real` = false (no next footprint):
     // every lane reads the first pixel of the current footprint -- one cache line, no branch around the loads.
     const unsigned lrow = (unsigned)(PPT * (lane >> 4)) * (unsigned)P.W + (unsigned)(lane & 15);   // pixel 0 of the strip, relative to (fy0, fx0)
+    const bool all_valid = (long long)P.n_valid == (long long)P.H * (long long)P.W;   // wave-uniform (scalar registers)
     auto fetch = [&](int fx0, int yb, unsigned lrow, int lane_o, bool real) {   // (row base and offset come in as opaque per-footprint copies)
 #ifdef OBIA_ABL_NOLOAD
         real = false;   // ablation build: every lane reads the footprint's first pixel (no HBM traffic for features / mask)
@@ -396,8 +397,15 @@ __device__ __forceinline__ void slic_assign_body(
         unsigned off[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) off[j] = (real && (yb + j < P.H) && (xx < P.W)) ? lrow + (unsigned)j * (unsigned)P.W : 0u;
+        // a problem whose mask hides nothing (every interior tile of the tiler: n_valid == H * W, counted by
+        // count_valid_kernel) reads no mask bytes -- four of the twelve load instructions of a footprint (wave-uniform branch)
+        if (MASKED && !all_valid) {
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) mb[j] = MASKED ? mbase[off[j]] : (unsigned char)1;
+            for (int j = 0; j < PPT; ++j) mb[j] = mbase[off[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) mb[j] = (unsigned char)1;
+        }
         if (!LEAN && want_feat) {
             // quad-row blocks (slic.hpp): ONE 16-byte load per channel brings that channel of the lane's four pixels, the
             // channels are 256 bytes apart (immediate offsets), a quarter wave reads 256 contiguous bytes and the footprint's
