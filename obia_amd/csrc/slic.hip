@@ -750,10 +750,9 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     const int RS = CENT_REC + b.CP;
     b.d_cent = A.get<float>((size_t)b.total_cent * RS);
     b.d_head = A.get<int>((size_t)b.total_cells * 2);
-    b.d_next = A.get<int>(b.total_cent);
     const size_t acc_q = (size_t)b.total_cent * acc_record_qwords(b.CP);
     b.d_acc = A.get<unsigned long long>(acc_q);
-    if (!b.d_cent || !b.d_head || !b.d_next || !b.d_acc) return OBIA_E_NOMEM;
+    if (!b.d_cent || !b.d_head || !b.d_acc) return OBIA_E_NOMEM;
     OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * acc_q, ctx->stream));
     return OBIA_OK;
 }

@@ -85,7 +85,7 @@ struct SlicBatch {
     int *d_cent_prob = nullptr;        // [total_cent]
     int *d_tile_prob = nullptr;        // [total_tiles_all] problem of every sweep tile, tiles numbered problem by problem in raster order
     float *d_cent = nullptr;           // [total_cent][8 + CP] records
-    int *d_head = nullptr, *d_next = nullptr;   // d_head: two buffers of total_cells (double-buffered per sweep)
+    int *d_head = nullptr;   // two buffers of total_cells (double-buffered per sweep); list links ride in the centroid records
     int *d_head_cur = nullptr;
     unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
     double fscale = 1.0;

@@ -78,7 +78,7 @@ constexpr int MAXC = SWEEP_MAXC;   // LDS candidate slots (two scoring rounds of
                                 // rides in the low 7 bits of the scoring keys
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
-// write the centroid record {cy, cx, y0, y1, x0, x1, k, -, colour[CP]} and push the centroid on the
+// write the centroid record {cy, cx, y0, y1, x0, x1, link, -, colour[CP]} (link: next centroid of the bin's list) and push the centroid on the
 // linked list of the bin that holds its current position.
 // G = RQ lanes per centroid: lane q of a group owns qword q of the 128-B (256-B) accumulator record, so the record is
 // read and cleared with one coalesced access per wave; n and the coordinate sums reach the group by shuffle.
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
                                                         int first, int slic_zero, const float *__restrict__ seed,
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
-                                                        int *__restrict__ next, int *__restrict__ head_other,
+                                                        int *__restrict__ head_other,
                                                         int total_cells, int *__restrict__ bin_stamp, int sweep_id) {
     // exit_on_fixed_point: a centroid whose record differs from the previous sweep's stamps the bin it leaves and the
     // bin it enters with the sweep number; the sweep kernel skips a tile none of whose bins was stamped since the tile
@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     float4 *hrec = reinterpret_cast<float4 *>(rec);   // records are 16-byte aligned (RS is a multiple of 4)
     if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
         hrec[0] = make_float4(cy, cx, 0.0f, 0.0f);
-        hrec[1] = make_float4(0.0f, 0.0f, __int_as_float(k), mdc);
-        next[k] = -1;
+        hrec[1] = make_float4(0.0f, 0.0f, __int_as_float(-1), mdc);
         return;
     }
     // z/y/x window of _slic_cython: (ssize_t)max(c - 2*step, 0) .. (ssize_t)min(c + 2*step + 1, size)
@@ -169,12 +168,14 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
     float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
     float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
-    hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
-    hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(k), mdc);
     int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
     by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
     bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
-    next[k] = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+    // the link to the next centroid of the bin's list rides in slot 6 of the record (a centroid's index is its record's index):
+    // a list node is ONE 32-byte read, not a read plus a lone dword from a second array
+    const int link = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+    hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
+    hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(link), mdc);
     if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
 }
 
@@ -230,7 +231,7 @@ __device__ __forceinline__ void global_accumulate(unsigned long long *__restrict
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool SLICZERO>
 __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *__restrict__ feat,
                           const uint8_t *__restrict__ mask, const float *__restrict__ cent,
-                          const int *__restrict__ head, const int *__restrict__ next, int32_t *__restrict__ labels,
+                          const int *__restrict__ head, int32_t *__restrict__ labels,
                           unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color, int start_label,
                           float fs, int store_labels, int *__restrict__ orphan_flag) {
     constexpr int RS = CENT_REC + CP;
@@ -251,7 +252,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
         int bk = -1;
         for (int by = by_lo; by <= by_hi; ++by)
             for (int bx = bx_lo; bx <= bx_hi; ++bx)
-                for (int cur = head[P.cell_off + by * P.ncx + bx]; cur >= 0; cur = next[cur]) {
+                for (int cur = head[P.cell_off + by * P.ncx + bx]; cur >= 0; cur = reinterpret_cast<const int *>(cent + (size_t)cur * RS)[6]) {
                     const float *rec = cent + (size_t)cur * RS;
                     const int *irec = reinterpret_cast<const int *>(rec);
                     if (!(y >= irec[2] && y < irec[3] && x >= irec[4] && x < irec[5])) continue;
@@ -290,7 +291,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN, bool COLLB>
 __device__ __forceinline__ void slic_assign_body(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
-    const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,
+    const float *__restrict__ cent, const int *__restrict__ head,
     int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int store_labels,
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
@@ -483,7 +484,7 @@ __device__ __forceinline__ void slic_assign_body(
 #pragma unroll
             for (int q = 0; q < CP / 4; ++q) rcol[q] = src[2 + q];
         }
-        nxt = next[c];
+        nxt = __float_as_int(r1.z);   // the link rides in the record
     };
     if (cur >= 0) load_node(cur);
     __syncthreads();
@@ -498,7 +499,7 @@ __device__ __forceinline__ void slic_assign_body(
                 const int slot = atomicAdd(&s_cnt, 1);
                 if (slot < MAXC) {
                     float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
-                    dh[0] = r0; dh[1] = r1;
+                    dh[0] = r0; dh[1] = make_float4(r1.x, r1.y, __int_as_float(cur), r1.w);   // (slot 6 of the LDS copy: k)
                     s_k[slot] = cur;
                     if (COLLB) {
 #pragma unroll
@@ -514,7 +515,7 @@ __device__ __forceinline__ void slic_assign_body(
     STAMP(1)   // prologue + staging (up to its barrier)
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
-        slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, next, labels, acc, RQ, accumulate,
+        slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
                                                       accum_color, start_label, fs, store_labels, orphan_flag);
         return;
     }
@@ -955,14 +956,14 @@ __device__ __forceinline__ void slic_assign_body(
 
 #define OBIA_ASSIGN_PARAMS                                                                                             \
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,             \
-        const float *__restrict__ cent, const int *__restrict__ head, const int *__restrict__ next,                      \
+        const float *__restrict__ cent, const int *__restrict__ head,                                                    \
         int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int store_labels,     \
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
         int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox
 #define OBIA_ASSIGN_ARGS                                                                                               \
-    probs, feat, mask, cent, head, next, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
+    probs, feat, mask, cent, head, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
         cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox
 
 // the colour sweeps and the last pre-pass sweep
@@ -1032,19 +1033,19 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     for (auto &P : b.probs) if (P.tiles_x * P.tiles_y != tpp) tpp = 0;
 #define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
-                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
                        use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
 #define LAUNCH_COLLB_(M)                                                                                            \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, ctx->stream, b.d_probs,   \
-                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate,       \
+                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
                        use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
-                       b.d_mask, b.d_cent, b.d_head_cur, b.d_next, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
+                       b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
                        b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
                        (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
@@ -1124,11 +1125,11 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 if (RQ == 16)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv((long long)b.total_cent * 16, 256)), dim3(256), 0,
                                        ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                       1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv((long long)b.total_cent * 32, 256)), dim3(256), 0,
                                        ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                       1.0 / b.fscale, b.d_cent, head_cur, b.d_next, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
                 b.d_head_cur = head_cur;
                 first = false;
                 if (zmode == 1) {   // the centroids just moved: raise max_dist_color from the assignment of the last sweep
