@@ -1,6 +1,11 @@
-"""Diagnostic (tools/build_variant.sh tl -DOBIA_STAMP, then OBIA_HIP_LIB=obia_amd/csrc/libobia_hip_tl.so): per-wave timeline of the
-LAST sweep launch of the colour pass on one 4096^2 x 8 raster (4096 tiles): phase cycles per wave, workgroup lifetimes, how many
-workgroups were alive on average.  s_memtime ticks."""
+"""Diagnostic: per-wave timeline of the SLIC colour sweep (the sweep before the last of one call) on one 4096^2 x 8 raster.
+   tools/build_variant.sh tl -DOBIA_STAMP                                   # stamps on, records per wave, no atomics
+   OBIA_HIP_LIB=obia_amd/csrc/libobia_hip_tl.so python tools/timeline_run.py
+   tools/build_variant.sh tl1 -DOBIA_STAMP -DOBIA_ABL_LDSPAD=110000          # + LDS ballast: ONE workgroup per CU (pure chain latency)
+Environment: TL_ITERS (sweeps per call, default 4), TL_MASK=1 (masked path: pre-pass + colour pass), TL_COMPACT (compactness, default 10).
+Prints phase cycles per wave (s_memtime ticks = core clock, checked against the 100-MHz clock), the wave lifetime and the visit counters.
+Other ablation switches of slic_sweep.hip: -DOBIA_ABL_NOLOAD (no feature / mask traffic), -DOBIA_ABL_VISITS=n (at most n visits per
+footprint), -DOBIA_ABL_NOACC (no centroid update).  Numbers: profiles/r02_pmc_notes.md."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
