@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restric
 }
 
 // flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
-__global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n) {
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n,
+                                                         unsigned long long *__restrict__ rootbits) {
     // four pixels per lane, chased in lockstep: the dependent parent loads of the four chains are in flight together
     constexpr int FU = 4;
     for (long long i0 = (long long)blockIdx.x * blockDim.x * FU; i0 < n; i0 += (long long)gridDim.x * blockDim.x * FU) {
@@ -218,6 +219,14 @@ __global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ paren
                 }
             if (!any) break;
         }
+        // one bit per pixel: "is a root".  The ranking passes read this map (1/8 byte per pixel) and the sizes of the roots instead
+        // of parent[] and size[] of every pixel (a wave's 64 pixels are consecutive and 64-aligned: one word per wave and u)
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const unsigned long long bal = __ballot(r[u] >= 0 && r[u] == (int)idx[u]);
+            const long long first = idx[u] - (threadIdx.x & 63);
+            if ((threadIdx.x & 63) == 0 && first < n) rootbits[first >> 6] = bal;
+        }
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             if (r[u] < 0) continue;
@@ -236,13 +245,15 @@ constexpr int SCAN_NT = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_NT * SCAN_PER;
 __global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProblem *__restrict__ probs, int nprob,
                                                                    const int *__restrict__ parent, const int *__restrict__ size,
                                                                    long long n, int *__restrict__ block_sums,
-                                                                   int *__restrict__ counters /*[0]=n_small [1]=small_px*/) {
+                                                                   int *__restrict__ counters /*[0]=n_small [1]=small_px*/,
+                                                                   const unsigned long long *__restrict__ rootbits /* null: test parent[] */) {
     __shared__ int s_w[SCAN_NT / 64], s_ws[SCAN_NT / 64], s_wp[SCAN_NT / 64];
     const long long base = (long long)blockIdx.x * SCAN_CHUNK;
     int c = 0, nsmall = 0, spx = 0, nbig = 0;
     for (int j = 0; j < SCAN_PER; ++j) {
         const long long i = base + (long long)j * SCAN_NT + threadIdx.x;
-        if (i < n && parent[i] == (int)i) {
+        const bool root = i < n && (rootbits ? ((rootbits[i >> 6] >> (threadIdx.x & 63)) & 1ull) != 0ull : parent[i] == (int)i);
+        if (root) {
             const int sz = size[i];
             const CcProblem &P = probs[find_prob(probs, nprob, i)];
             if (sz >= P.min_size) c += 1;
@@ -376,7 +387,8 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
                                                                 const int *__restrict__ parent, const int *__restrict__ size,
                                                                 long long n, const int *__restrict__ block_sums,
                                                                 int *__restrict__ newlab, int *__restrict__ small_list,
-                                                                int *__restrict__ small_qoff, int *__restrict__ counters) {
+                                                                int *__restrict__ small_qoff, int *__restrict__ counters,
+                                                                const unsigned long long *__restrict__ rootbits /* null: test parent[] */) {
     (void)counters;
     __shared__ int s_w[SCAN_NT / 64], s_ws[SCAN_NT / 64], s_wp[SCAN_NT / 64];
     __shared__ int s_run, s_srun, s_prun;   // next survivor label, next slot of the small list, next queue offset
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
         int flag = 0;
         bool small = false;
         int sz = 0;
-        if (i < n && parent[i] == (int)i) {
+        if (i < n && (rootbits ? ((rootbits[i >> 6] >> lane) & 1ull) != 0ull : parent[i] == (int)i)) {
             sz = size[i];
             flag = sz >= probs[find_prob(probs, nprob, i)].min_size;
             small = !flag;
@@ -544,6 +556,9 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *parent = A.get<int>(n), *size = A.get<int>(n), *newlab = A.get<int>(n);
     const int nb = cdiv(n, SCAN_CHUNK);
     int *block_sums = A.get<int>(3 * (size_t)nb);   // survivors | small components | their pixels (cc_rank_blocksum_kernel)
+    unsigned long long *rootbits = A.get<unsigned long long>((size_t)((n + 63) / 64));   // one bit per pixel: root (cc_flatten_kernel)
+    if (!rootbits) return OBIA_E_NOMEM;
+    const unsigned long long *rb = rootbits;   // the map the ranking passes read; null once the size cut has changed the roots
     int *counters = A.get<int>(8);
     if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
     OBIA_TRY(upload_async(ctx, d_probs, probs.data(), sizeof(CcProblem) * np));
@@ -564,8 +579,8 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         if (sg > 65535) sg = 65535;
         hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
     }
-    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n);
-    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n, rootbits);
+    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters, rb);
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
     int hc[8];
     OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));   // also orders the pageable `probs` upload
@@ -585,7 +600,8 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         hipLaunchKernelGGL(cc_split_kernel, dim3(cdiv(n_big, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, size, big_root, big_qoff,
                            big_box, n_big, bqueue);
         OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
-        hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters);
+        rb = nullptr;   // cc_split_kernel made new roots: the ranking passes test parent[] again
+        hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters, rb);
         hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
         OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));
     }
@@ -596,7 +612,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *queue = A.get<int>(small_px > 0 ? small_px : 1);
     if (!small_list || !small_qoff || !target || !queue) return OBIA_E_NOMEM;
     hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
-                       newlab, small_list, small_qoff, counters);
+                       newlab, small_list, small_qoff, counters, rb);
     if (n_small > 0) {
         int *settle_a = A.get<int>(n_small), *settle_b = A.get<int>(n_small);
         if (!settle_a || !settle_b) return OBIA_E_NOMEM;
