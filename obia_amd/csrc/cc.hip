@@ -356,6 +356,78 @@ __global__ __launch_bounds__(64) void cc_split_kernel(const CcProblem *__restric
         }
 }
 
+// The same two passes on the root bitmap of cc_flatten_kernel (the usual path: no component was cut): ONE wave per chunk of
+// SCAN_CHUNK = 64 x 64 pixels, lane l owns bitmap word l and walks its set bits (a root every few hundred pixels: a lane holds
+// none, one or two) -- no barriers, no pass over parent[] / size[] of every pixel; sums and prefixes over the wave by shuffles.
+static_assert(SCAN_CHUNK == 64 * 64, "one wave per chunk: 64 bitmap words");
+__global__ __launch_bounds__(64) void cc_rank_blocksum_bits_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                                    const int *__restrict__ size, long long n,
+                                                                    int *__restrict__ block_sums, int *__restrict__ counters,
+                                                                    const unsigned long long *__restrict__ rootbits) {
+    const int lane = threadIdx.x;
+    const long long w = (long long)blockIdx.x * 64 + lane, nw = (n + 63) >> 6;
+    unsigned long long bits = w < nw ? rootbits[w] : 0ull;
+    int c = 0, nsmall = 0, spx = 0, nbig = 0;
+    while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const long long i = (w << 6) + b;
+        const int sz = size[i];
+        const CcProblem &P = probs[find_prob(probs, nprob, i)];
+        if (sz >= P.min_size) c += 1;
+        else { nsmall += 1; spx += sz; }
+        if (sz >= P.max_size && sz > 1) nbig += 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c += __shfl_xor(c, off); nsmall += __shfl_xor(nsmall, off); spx += __shfl_xor(spx, off); nbig += __shfl_xor(nbig, off);
+    }
+    if (lane == 0) {
+        block_sums[blockIdx.x] = c;
+        block_sums[gridDim.x + blockIdx.x] = nsmall;
+        block_sums[2 * gridDim.x + blockIdx.x] = spx;
+        if (nbig) atomicAdd(&counters[6], nbig);
+    }
+}
+
+__global__ __launch_bounds__(64) void cc_rank_apply_bits_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                                 const int *__restrict__ size, long long n,
+                                                                 const int *__restrict__ block_sums, int *__restrict__ newlab,
+                                                                 int *__restrict__ small_list, int *__restrict__ small_qoff,
+                                                                 const unsigned long long *__restrict__ rootbits) {
+    const int lane = threadIdx.x;
+    const long long w = (long long)blockIdx.x * 64 + lane, nw = (n + 63) >> 6;
+    const unsigned long long word = w < nw ? rootbits[w] : 0ull;
+    // first walk: this lane's counts; exclusive prefixes over the lanes; second walk: the labels / slots in raster order
+    int c = 0, ns = 0, px = 0;
+    for (unsigned long long bits = word; bits; bits &= bits - 1) {
+        const long long i = (w << 6) + __builtin_ctzll(bits);
+        const int sz = size[i];
+        if (sz >= probs[find_prob(probs, nprob, i)].min_size) c += 1;
+        else { ns += 1; px += sz; }
+    }
+    int pc = c, pn = ns, pp = px;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int tc = __shfl_up(pc, off), tn = __shfl_up(pn, off), tp = __shfl_up(pp, off);
+        if (lane >= off) { pc += tc; pn += tn; pp += tp; }
+    }
+    int run = block_sums[blockIdx.x] + pc - c, srun = block_sums[gridDim.x + blockIdx.x] + pn - ns,
+        prun = block_sums[2 * gridDim.x + blockIdx.x] + pp - px;
+    for (unsigned long long bits = word; bits; bits &= bits - 1) {
+        const long long i = (w << 6) + __builtin_ctzll(bits);
+        const int sz = size[i];
+        if (sz >= probs[find_prob(probs, nprob, i)].min_size) {
+            newlab[i] = run++;
+        } else {
+            small_list[srun] = (int)i;
+            small_qoff[srun] = prun;
+            newlab[i] = -(srun + 2);
+            srun += 1; prun += sz;
+        }
+    }
+}
+
 // exclusive scan of block_sums in place, single workgroup; total -> counters[2]
 __global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ block_sums_all, int nb, int *__restrict__ counters) {
     __shared__ int s_part[1024];
@@ -363,7 +435,9 @@ __global__ __launch_bounds__(1024) void cc_rank_scan_kernel(int *__restrict__ bl
     const int per = (nb + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, nb);
     // segment 0: survivors -> counters[2]; 1: small components -> counters[0]; 2: their pixels -> counters[1]
-    for (int seg = 0; seg < 3; ++seg) {
+    // (one workgroup per segment: grid = 3)
+    {
+        const int seg = blockIdx.x;
         int *block_sums = block_sums_all + (size_t)seg * nb;
         int s = 0;
         for (int i = lo; i < hi; ++i) s += block_sums[i];
@@ -580,8 +654,8 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
     }
     hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n, rootbits);
-    hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters, rb);
-    hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
+    hipLaunchKernelGGL(cc_rank_blocksum_bits_kernel, dim3(nb), dim3(64), 0, ctx->stream, d_probs, np, size, n, block_sums, counters, rootbits);
+    hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(3), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
     int hc[8];
     OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));   // also orders the pageable `probs` upload
     if (hc[6] > 0) {
@@ -602,7 +676,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
         rb = nullptr;   // cc_split_kernel made new roots: the ranking passes test parent[] again
         hipLaunchKernelGGL(cc_rank_blocksum_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums, counters, rb);
-        hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
+        hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(3), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
         OBIA_TRY(read_back(ctx, hc, counters, sizeof(hc)));
     }
     const int n_small = hc[0], small_px = hc[1], n_surv = hc[2];
@@ -611,8 +685,12 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *target = A.get<int>(n_small > 0 ? n_small : 1);
     int *queue = A.get<int>(small_px > 0 ? small_px : 1);
     if (!small_list || !small_qoff || !target || !queue) return OBIA_E_NOMEM;
-    hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
-                       newlab, small_list, small_qoff, counters, rb);
+    if (rb)
+        hipLaunchKernelGGL(cc_rank_apply_bits_kernel, dim3(nb), dim3(64), 0, ctx->stream, d_probs, np, size, n, block_sums, newlab,
+                           small_list, small_qoff, rb);
+    else
+        hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
+                           newlab, small_list, small_qoff, counters, rb);
     if (n_small > 0) {
         int *settle_a = A.get<int>(n_small), *settle_b = A.get<int>(n_small);
         if (!settle_a || !settle_b) return OBIA_E_NOMEM;
