@@ -509,42 +509,55 @@ __global__ __launch_bounds__(256) void seed_masked_kernel(const SeedGrid *__rest
                                                           const SlicProblem *__restrict__ probs,
                                                           const uint8_t *__restrict__ mask, float *__restrict__ seed,
                                                           int *__restrict__ cent_prob, int *__restrict__ K_out) {
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
+    constexpr int U = 4;                      // grid points per thread and step: four mask bytes in flight (the step is one
+    __shared__ int s_wave[2][U][4];           // memory round trip long), kept counts per (sub-chunk, wave), double-buffered by step
     __shared__ unsigned long long s_first;
     const int p = blockIdx.x;
     const SeedGrid g = grids[p];
     const SlicProblem P = probs[p];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { s_base = 0; s_first = ~0ull; }
-    __syncthreads();
+    if (tid == 0) s_first = ~0ull;
     const int Kg = g.ny * g.nx;
-    for (int k0 = 0; k0 < Kg; k0 += 256) {
-        const int k = k0 + tid;
-        int y = 0, x = 0;
-        bool keep = false;
-        if (k < Kg) {
-            y = g.start_y + (k / g.nx) * g.step_y;
-            x = g.start_x + (k % g.nx) * g.step_x;
-            keep = mask[P.pix_off + (long long)y * P.W + x] != 0;
+    int base = 0;                             // seeds kept so far (the same in every thread: no shared counter, one barrier per step)
+    for (int k0 = 0, it = 0; k0 < Kg; k0 += U * 256, ++it) {
+        int y[U], x[U];
+        bool keep[U];
+        unsigned long long bal[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 256 + tid;
+            y[u] = x[u] = 0;
+            keep[u] = false;
+            if (k < Kg) {
+                y[u] = g.start_y + (k / g.nx) * g.step_y;
+                x[u] = g.start_x + (k % g.nx) * g.step_x;
+                keep[u] = mask[P.pix_off + (long long)y[u] * P.W + x[u]] != 0;
+            }
         }
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_wave[wv] = __popcll(bal);
-        __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wv; ++w) before += s_wave[w];
-        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        const int rank = s_base + before + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep) {
-            seed[2 * (size_t)(g.cent_off + rank)] = (float)y;
-            seed[2 * (size_t)(g.cent_off + rank) + 1] = (float)x;
-            cent_prob[g.cent_off + rank] = p;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bal[u] = __ballot(keep[u]);
+            if (lane == 0) s_wave[it & 1][u][wv] = __popcll(bal[u]);
         }
         __syncthreads();
-        if (tid == 0) s_base += total;
-        __syncthreads();
+        int run = base;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = s_wave[it & 1][u][w]; total += c; if (w < wv) before += c; }
+            if (keep[u]) {
+                const int rank = run + before + __popcll(bal[u] & ((1ull << lane) - 1ull));
+                seed[2 * (size_t)(g.cent_off + rank)] = (float)y[u];
+                seed[2 * (size_t)(g.cent_off + rank) + 1] = (float)x[u];
+                cent_prob[g.cent_off + rank] = p;
+            }
+            run += total;
+        }
+        base = run;
     }
-    int K = s_base;
+    __syncthreads();
+    int K = base;
     if (K == 0) {
         const long long npix = (long long)P.H * P.W;
         unsigned long long best = ~0ull;
