@@ -653,7 +653,9 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         if (sg > 65535) sg = 65535;
         hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
     }
+    debug_sync(ctx, "cc: tile + seam");
     hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n, rootbits);
+    debug_sync(ctx, "cc: flatten");
     hipLaunchKernelGGL(cc_rank_blocksum_bits_kernel, dim3(nb), dim3(64), 0, ctx->stream, d_probs, np, size, n, block_sums, counters, rootbits);
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(3), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
     int hc[8];
@@ -685,6 +687,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *target = A.get<int>(n_small > 0 ? n_small : 1);
     int *queue = A.get<int>(small_px > 0 ? small_px : 1);
     if (!small_list || !small_qoff || !target || !queue) return OBIA_E_NOMEM;
+    debug_sync(ctx, "cc: rank counts");
     if (rb)
         hipLaunchKernelGGL(cc_rank_apply_bits_kernel, dim3(nb), dim3(64), 0, ctx->stream, d_probs, np, size, n, block_sums, newlab,
                            small_list, small_qoff, rb);
@@ -699,10 +702,12 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         // optimistic start (every small component labelled at its first pixel), then Jacobi rounds until the
         // settle times stop moving; one round settles everything unless small components that find no
         // labelled neighbour touch each other
-        // (settle times only move forward and are bounded, so the rounds end; a chain of k small components that touch
-        // each other needs at most k rounds -- never cut short: an unconverged round would write label 0)
+        // (settle times only move forward, and a component's settle time is one of its own pixels or "never": the rounds end
+        // after at most small_px + 1 of them.  Usually one or two; a handful of small components that only touch each other can
+        // need more rounds than there are components -- found by tests/test_gpu_tiling_random.py -- so the bound is the pixel
+        // count, not the component count.  Never cut short: an unconverged round would write label 0)
         bool converged = false;
-        for (int round = 0; round <= n_small + 1; ++round) {
+        for (long long round = 0; round <= (long long)small_px + 1; ++round) {
             OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
                                small_list, small_qoff, n_small, start_label, settle_a, settle_b, queue, labels_out, target,
@@ -714,6 +719,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         }
         if (!converged) { set_error("connectivity enforcement: settle rounds did not converge (%d small components)", n_small); return OBIA_E_INVALID; }
     }
+    debug_sync(ctx, "cc: rank apply + small components");
     hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
                        mask_label, n_small + 1, labels_out);
     OBIA_HIP_TRY(hipGetLastError());

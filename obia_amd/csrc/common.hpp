@@ -98,6 +98,9 @@ int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 // (pageable, short-lived) buffer is free at once; the ring is recycled at the next read_back (everything queued before it
 // has then executed).
 int upload_async(obia_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+// Developer aid (OBIA_DEBUG_SYNC=1): synchronise the stream and report the stage on stderr, so that an asynchronous GPU fault
+// is pinned on the stage that caused it.  A no-op otherwise.
+void debug_sync(obia_ctx *ctx, const char *stage);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -153,6 +153,14 @@ int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) 
     return OBIA_OK;
 }
 
+void debug_sync(obia_ctx *ctx, const char *stage) {
+    static const bool on = std::getenv("OBIA_DEBUG_SYNC") != nullptr;
+    if (!on) return;
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    fprintf(stderr, "[obia debug] %s: %s\n", stage, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+}
+
 int upload_async(obia_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
     if (bytes == 0) return OBIA_OK;
     constexpr size_t RING = 8u << 20;

@@ -487,7 +487,7 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
 // ------------------------------------------------------------------------------------------------
 // seeding
 // ------------------------------------------------------------------------------------------------
-struct SeedGrid { int start_y, step_y, ny, start_x, step_x, nx; int cent_off; int pad; };
+struct SeedGrid { int start_y, step_y, ny, start_x, step_x, nx; int cent_off; int slots; };   // slots: centroid records reserved for the problem (0: empty problem)
 
 // unmasked: centroid k of problem p sits on the regular grid (slic_superpixels.py:71-104)
 __global__ void seed_grid_kernel(const SeedGrid *__restrict__ grids, int nprob, float *__restrict__ seed,
@@ -558,7 +558,10 @@ __global__ __launch_bounds__(256) void seed_masked_kernel(const SeedGrid *__rest
     }
     __syncthreads();
     int K = base;
-    if (K == 0) {
+    // fallback seed (no grid point is valid): only for a problem that HAS a record reserved.  An "empty" problem -- no valid
+    // pixel, or so few that n_segments rounds to zero -- reserved none: writing its fallback seed went one element past
+    // d_seed / d_cent_prob (found by tests/test_gpu_tiling_random.py: a 35 x 53 window with 55 valid pixels).
+    if (K == 0 && g.slots > 0) {
         const long long npix = (long long)P.H * P.W;
         unsigned long long best = ~0ull;
         for (long long i = tid; i < npix; i += 256)
@@ -663,7 +666,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         SlicProblem &P = b.probs[p];
         P.n_valid = nvalid[p];
         SeedGrid &g = grids[p];
-        g.cent_off = cent_off; g.pad = 0;
+        g.cent_off = cent_off; g.slots = 0;
         if (ext && nvalid[p] > 0) {   // seeds given by the caller: K = their number, step = max(steps) of the seeding
             g.start_y = g.start_x = 0; g.step_y = g.step_x = 1; g.ny = 1; g.nx = ext->n;
             stepmax[p] = ext->step < 1.0 ? 1.0 : ext->step;
@@ -693,6 +696,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         long long Kg = (long long)g.ny * g.nx;
         if (Kg < 1) Kg = 1;   // masked fallback seed
         if (cent_off + Kg > 0x7fff0000LL) { set_error("too many centroids in one batch"); return OBIA_E_INVALID; }
+        g.slots = (int)Kg;
         cent_off += (int)Kg;
     }
     b.total_cent = cent_off > 0 ? cent_off : 1;

@@ -1077,6 +1077,14 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
     };
     fill_labels();
+    debug_sync(ctx, "sweeps: label fill");
+    if (std::getenv("OBIA_DEBUG_SYNC"))
+        for (size_t p = 0; p < b.probs.size(); ++p) {
+            const SlicProblem &P = b.probs[p];
+            fprintf(stderr, "[obia debug]   problem %zu: %dx%d K %d steps %d %d bins %dx%d cell_off %d cent_off %d tiles %dx%d tile_off %d n_valid %d (total_cent %d total_cells %d tiles_all %lld)\n",
+                    p, P.H, P.W, P.K, P.sy, P.sx, P.ncy, P.ncx, P.cell_off, P.cent_off, P.tiles_y, P.tiles_x, P.tile_off, P.n_valid,
+                    b.total_cent, b.total_cells, b.total_tiles_all);
+        }
     if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
     // the sweep addresses a footprint's pixels as a 64-bit wave-uniform base plus a 32-bit lane offset (16 rows x W x 64 B)
     for (auto &P : b.probs)
@@ -1111,6 +1119,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     auto run_all = [&](bool store_all) -> int {
         OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 513, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
+        debug_sync(ctx, "sweeps: memsets");
         bool first = true;
         int sweep_no = 0;
         for (int pass = 0; pass < passes; ++pass) {
@@ -1131,6 +1140,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                                        ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
                                        1.0 / b.fscale, b.d_cent, head_cur, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
                 b.d_head_cur = head_cur;
+                debug_sync(ctx, "sweeps: prep");
                 first = false;
                 if (zmode == 1) {   // the centroids just moved: raise max_dist_color from the assignment of the last sweep
                     dim3 zg(maxh_z, b.nprob);
@@ -1169,6 +1179,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                         default: set_error("bad CP"); return OBIA_E_INVALID;
                     }
                 }
+                debug_sync(ctx, ignore_color ? "sweeps: pre-pass sweep" : "sweeps: colour sweep");
             }
         }
         OBIA_HIP_TRY(hipGetLastError());

@@ -359,7 +359,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp.compactness), &skip));
     }
     std::vector<int> nvalid;
+    debug_sync(ctx, "tiler: mask + features");
     OBIA_TRY(slic_count_valid(ctx, b, nvalid));
+    debug_sync(ctx, "tiler: count_valid");
     std::vector<int> nseg(np);
     const double pixel_area = S.tp.pixel_width * S.tp.pixel_height;
     const double crown_area = M_PI * S.tp.crown_radius * S.tp.crown_radius;
@@ -372,7 +374,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         nseg[p] = (skip[p] || n < 1.0) ? 0 : (n > 2.0e9 ? 2000000000 : (int)n);   // empty tile -> skipped (tiling.py:149-150)
     }
     OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, &nvalid));
+    debug_sync(ctx, "tiler: plan_and_seed");
     OBIA_TRY(slic_run_sweeps(ctx, b));
+    debug_sync(ctx, "tiler: sweeps");
     int n_new = 0;
     if (S.sp.enforce_connectivity) {
         std::vector<CcProblem> cps(np);
@@ -384,6 +388,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
             cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp.min_size_factor * segment_size), mx > 0 ? mx : 1};
         }
         OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new));
+        debug_sync(ctx, "tiler: connectivity");
     } else {
         set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)");
         return OBIA_E_UNSUPPORTED;

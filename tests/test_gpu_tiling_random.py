@@ -1,0 +1,55 @@
+"""Randomised parity of the tiled driver against oracle/tiler.py: seeded geometries (raster sizes off every grid, tile sizes,
+buffers, crown radii, pixel sizes), 1..9 bands except 3 (no Lab: the per-tile SLIC is then bit-exact), compactness from 0.25 to 10,
+masks with holes / empty tiles / thin pieces.  Bar: the label rasters are IDENTICAL pixel for pixel and the segment counts equal;
+ids are 1..N.  (oracle/tiler.py itself stays "parity unpinned", DESIGN.md 2: this pins the HIP tile loops on the restatement.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make_case(seed):
+    rs = np.random.RandomState(7000 + seed)
+    H = int(rs.randint(120, 330))
+    W = int(rs.randint(120, 360))
+    C = int(rs.choice([1, 2, 4, 5, 8, 9]))
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.stack([350 * np.sin(xx / (9 + 3 * c)) * np.cos(yy / (12 + 2 * c)) + 900 + 60 * c + rs.normal(0, 22, (H, W))
+                    for c in range(C)], -1).astype(np.float32)
+    tile = int(rs.choice([64, 80, 100, 128, 150]))
+    buf = int(rs.choice([8, 12, 16, 24, 30]))
+    kw = dict(tile_size=tile, buffer=buf, crown_radius=float(rs.choice([3, 4, 5, 6])),
+              pixel_size=(float(rs.choice([0.5, 1.0])),) * 2, compactness=float(rs.choice([0.25, 1.0, 10.0])))
+    mask = None
+    kind = rs.randint(0, 4)
+    if kind == 1:      # disc with a rectangular hole
+        mask = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (0.48 * max(H, W)) ** 2) & ~((abs(yy - H / 3) < H / 9) & (abs(xx - W / 2) < W / 7))
+    elif kind == 2:    # a masked corner (empties whole tiles) and a diagonal band
+        mask = np.ones((H, W), bool)
+        mask[:tile, :tile] = False
+        mask &= (abs(xx - yy * W / H) > 6)
+    elif kind == 3:    # scattered rectangles
+        mask = np.zeros((H, W), bool)
+        for _ in range(5):
+            y0, x0 = rs.randint(0, H - 20), rs.randint(0, W - 20)
+            mask[y0:y0 + rs.randint(20, H // 2), x0:x0 + rs.randint(20, W // 2)] = True
+    return img, mask, kw
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OBIA_RANDOM_TILER_CASES", "40"))))
+def test_random_tiled_case_vs_oracle(oracle, seed):
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    img, mask, kw = make_case(seed)
+    ref, n_ref = tiler.create_tiled_segments(img, mask, **kw)
+    lab, n = create_tiled_segments(torch.as_tensor(img).cuda(), input_mask=mask, **kw)
+    lab = lab.cpu().numpy()
+    assert n == n_ref and np.array_equal(lab, ref), f"seed {seed} {img.shape} {kw}: {(lab != ref).sum()} px differ, n {n} vs {n_ref}"
+    if mask is not None:
+        assert (lab[~mask] == 0).all()
+    if n:
+        ids = np.unique(lab[lab > 0])
+        assert ids[0] == 1 and ids[-1] == n and len(ids) == n
