@@ -68,3 +68,10 @@ def test_random_case_vs_oracle(oracle, seed):
         assert adjusted_rand_index(lab[valid], ref[valid]) >= 0.99
     # a second run is bit-identical (integer accumulators)
     assert np.array_equal(slic(dev, mask=mask, _normalize_bands=True, **kw).cpu().numpy(), lab)
+    # exit_on_fixed_point (tile-level replay of cached partial sums) never changes a label
+    assert np.array_equal(slic(dev, mask=mask, _normalize_bands=True, exit_on_fixed_point=True, **kw).cpu().numpy(), lab)
+    if seed % 4 == 0:   # SLIC-zero (per-cluster colour scale) on the same case, against the oracle's
+        zref, zpre, _ = oracle.slic(oracle.normalize(img), return_all=True, slic_zero=True, **okw)
+        zl = slic(dev, mask=mask, _normalize_bands=True, slic_zero=True, **kw).cpu().numpy()
+        assert adjusted_rand_index(zl[valid], zref[valid]) >= 0.99, f"seed {seed}: SLIC-zero"
+
