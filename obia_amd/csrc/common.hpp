@@ -90,6 +90,13 @@ struct ScopedSpan {
     ScopedSpan(obia_ctx *c, int kind);
     ~ScopedSpan();
 };
+// The same bookkeeping for ONE kernel: the event pair is handed to hipExtLaunchKernelGGL, which binds it to the dispatch
+// itself, so the elapsed time is the kernel's own start-to-end (what a rocprofv3 kernel trace reports) and not the distance
+// between two stream markers around it (that also times the dispatch, a few microseconds).  Both null when profiling is off.
+struct KernelSpan {
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelSpan(obia_ctx *c, int kind);
+};
 void begin_timing(obia_ctx *ctx);
 void resolve_timing(obia_ctx *ctx);
 

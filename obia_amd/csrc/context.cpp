@@ -113,6 +113,13 @@ ScopedSpan::~ScopedSpan() {
     if (on) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
 }
 
+KernelSpan::KernelSpan(obia_ctx *c, int kind) {
+    if (!(c->profiling == 1 || (c->profiling == 2 && kind == T_ASSIGN))) return;
+    a = get_event(c);
+    b = get_event(c);
+    c->spans.push_back(obia_ctx::Span{kind, a, b});
+}
+
 void begin_timing(obia_ctx *ctx) {
     ctx->spans.clear();
     ctx->events_used = 0;

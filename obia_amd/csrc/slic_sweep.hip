@@ -33,6 +33,7 @@
 // A tile that meets more candidates than fit in LDS (tiny S, clustered centroids) takes slow_tile(), which
 // reads the bins directly; correctness never depends on the LDS capacity.
 #include "slic.hpp"
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -1025,26 +1026,27 @@ struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; 
 
 template <int CP>
 static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color, int store_labels,
-                          int *orphan_flag, const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter) {
+                          int *orphan_flag, const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter,
+                          const KernelSpan &span) {
     constexpr int XGH = OBIA_XCD_GROUP;
     dim3 grid(8 * XGH * (unsigned)(((int)b.total_tiles_all + 8 * XGH - 1) / (8 * XGH)));   // whole groups of 8 XCDs x XG tiles (see slic_assign_body)
     const int RQ = acc_record_qwords(CP);
     int tpp = b.probs.empty() ? 0 : b.probs[0].tiles_x * b.probs[0].tiles_y;   // tiles per problem if all problems agree, else 0
     for (auto &P : b.probs) if (P.tiles_x * P.tiles_y != tpp) tpp = 0;
 #define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, b.d_probs, \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, span.a, span.b, 0, b.d_probs, \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
                        use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
 #define LAUNCH_COLLB_(M)                                                                                            \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, ctx->stream, b.d_probs,   \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, ctx->stream, span.a, span.b, 0, b.d_probs,   \
                        b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
                        use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, b.d_probs, b.d_feat,   \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
                        b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
                        b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
                        (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
@@ -1168,14 +1170,14 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 // caches written by the earlier pre-pass sweeps hold no colour sums, so it evaluates every tile
                 const int use_cache = (ignore_color && it == b.max_iter - 1) ? 0 : 1;
                 {
-                    ScopedSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);
+                    KernelSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);   // events bound to the dispatch
                     unsigned long long *pxc = ctx->profiling ? d_px + (ignore_color ? 256 : 0) : nullptr;
                     if (ctx->profiling && !ignore_color && store_labels) ctx->timing.assign_store_px += (double)b.total_pix;
                     switch (b.CP) {
-                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
-                        case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
-                        case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
-                        case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc); break;
+                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
+                        case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
+                        case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
+                        case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
                         default: set_error("bad CP"); return OBIA_E_INVALID;
                     }
                 }
