@@ -276,11 +276,12 @@ def main():
     ctx.set_profiling(2)
     barrier()
     t0 = time.time()
-    assign_ms = assign_px = assign_store_px = sweeps = 0.0
+    assign_ms = assign_px = assign_store_px = sweeps = assign_busy_ms = 0.0
     n_seg = 0
     for _ in range(args.steps):
         lab, n_seg, st, t_seg, t_z = step()
         assign_ms += t_seg["assign_ms"]
+        assign_busy_ms += t_seg["assign_busy_ms"]
         assign_px += t_seg["assign_px"]
         assign_store_px += t_seg["assign_store_px"]
         sweeps += t_seg["sweeps"]
@@ -374,7 +375,8 @@ def main():
                          "bytes_per_pixel": round(alg_bytes / max(1.0, assign_px), 2), "launches": int(sweeps), "avg_launch_ms": round(avg_launch_ms, 4),
                          "bytes_note": "4C per pixel read + 4 per pixel written by the sweeps that store labels (1 in 10)",
                          "frac_at_survey_36B_per_px": round(achieved_survey / HBM_PEAK_GBS, 4),
-                         "pixels_per_launch_avg": round(assign_px / max(1.0, sweeps), 1)},
+                         "pixels_per_launch_avg": round(assign_px / max(1.0, sweeps), 1),
+                         "sweep_sum_ms_per_step": round(assign_ms / args.steps, 3), "sweep_busy_ms_per_step": round(assign_busy_ms / args.steps, 3)},
             "stage_ms_per_step": dict({k: round(v / max(1, parts_steps), 3) for k, v in parts.items()},
                                       source="one step after the timed region, every kernel class bracketed by events"),
         }

@@ -57,6 +57,9 @@ struct Timing {
     double assign_px = 0, prepass_px = 0;   // pixels processed by the timed colour / pre-pass sweeps (sum over launches)
     double assign_store_px = 0;             // ... of the colour sweeps that also stored their labels (the last sweep of a batch)
     int sweeps = 0;
+    // time during which at least one colour (pre-pass) sweep was running: equals assign_ms (prepass_ms) when the sweeps run one
+    // after the other, less when groups of problems run side by side (slic_run_sweeps)
+    double assign_busy_ms = 0, prepass_busy_ms = 0;
 };
 
 }  // namespace obia
@@ -77,6 +80,11 @@ struct obia_ctx {
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
+    // side streams of the sweep loop (slic_run_sweeps: groups of problems run their prep / sweep chains side by side, so
+    // that one group's sweep fills the ramp, the tail and the launch gaps of the others'); created on first use
+    static constexpr int MAX_SIDE = 3;
+    hipStream_t side[MAX_SIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_SIDE] = {nullptr, nullptr, nullptr};
 };
 
 namespace obia {
@@ -105,6 +113,7 @@ int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 // (pageable, short-lived) buffer is free at once; the ring is recycled at the next read_back (everything queued before it
 // has then executed).
 int upload_async(obia_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int side_streams(obia_ctx *ctx, int n);   // makes sure side[0..n) and their events exist
 // Developer aid (OBIA_DEBUG_SYNC=1): synchronise the stream and report the stage on stderr, so that an asynchronous GPU fault
 // is pinned on the stage that caused it.  A no-op otherwise.
 void debug_sync(obia_ctx *ctx, const char *stage);

@@ -1,6 +1,9 @@
 // context.cpp -- context lifetime, workspace arena, error string, timing spans.
 #include "common.hpp"
 
+#include <algorithm>
+#include <utility>
+
 #include <cstdarg>
 
 namespace obia {
@@ -113,6 +116,16 @@ ScopedSpan::~ScopedSpan() {
     if (on) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
 }
 
+int side_streams(obia_ctx *ctx, int n) {
+    if (n > obia_ctx::MAX_SIDE) n = obia_ctx::MAX_SIDE;
+    if (!ctx->fork_ev) OBIA_HIP_TRY(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < n; ++i) {
+        if (!ctx->side[i]) OBIA_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+        if (!ctx->join_ev[i]) OBIA_HIP_TRY(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
+    }
+    return OBIA_OK;
+}
+
 KernelSpan::KernelSpan(obia_ctx *c, int kind) {
     if (!(c->profiling == 1 || (c->profiling == 2 && kind == T_ASSIGN))) return;
     a = get_event(c);
@@ -129,9 +142,19 @@ void begin_timing(obia_ctx *ctx) {
 void resolve_timing(obia_ctx *ctx) {
     if (!ctx->profiling) return;
     (void)hipStreamSynchronize(ctx->stream);
+    // sweeps: [start, end) of every kernel on the clock of the first one (end = distance from the first kernel's start to this
+    // kernel's end, start = end - the kernel's own duration), for the length of their union
+    std::vector<std::pair<double, double>> iv[2];
+    hipEvent_t ref = nullptr;
     for (auto &s : ctx->spans) {
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, s.a, s.b);
+        if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) { (void)hipGetLastError(); continue; }   // (a launch that was skipped)
+        if (s.kind == T_ASSIGN || s.kind == T_PREPASS) {
+            if (!ref) ref = s.a;
+            float end = 0;
+            if (hipEventElapsedTime(&end, ref, s.b) == hipSuccess) iv[s.kind == T_ASSIGN ? 0 : 1].emplace_back((double)end - ms, (double)end);
+            else (void)hipGetLastError();
+        }
         switch (s.kind) {
             case T_ASSIGN: ctx->timing.assign_ms += ms; ctx->timing.sweeps += 1; break;
             case T_FEAT: ctx->timing.feat_ms += ms; break;
@@ -141,6 +164,16 @@ void resolve_timing(obia_ctx *ctx) {
             case T_PREPASS: ctx->timing.prepass_ms += ms; break;
             default: break;
         }
+    }
+    for (int c = 0; c < 2; ++c) {
+        std::sort(iv[c].begin(), iv[c].end());
+        double busy = 0, lo = 0, hi = -1;
+        for (auto &x : iv[c]) {
+            if (hi < lo || x.first > hi) { if (hi > lo) busy += hi - lo; lo = x.first; hi = x.second; }
+            else if (x.second > hi) hi = x.second;
+        }
+        if (hi > lo) busy += hi - lo;
+        (c == 0 ? ctx->timing.assign_busy_ms : ctx->timing.prepass_busy_ms) += busy;
     }
     ctx->spans.clear();
 }
@@ -245,6 +278,11 @@ void obia_destroy(obia_ctx *ctx) {
     if (ctx->up_buf) (void)hipHostFree(ctx->up_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < obia_ctx::MAX_SIDE; ++i) {
+        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+        if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -291,6 +329,8 @@ double obia_last_timing(obia_ctx *ctx, int what) {
         case 7: return ctx->timing.assign_px;
         case 8: return ctx->timing.prepass_px;
         case 9: return ctx->timing.assign_store_px;
+        case 10: return ctx->timing.assign_busy_ms;
+        case 11: return ctx->timing.prepass_busy_ms;
         default: return -1.0;
     }
 }

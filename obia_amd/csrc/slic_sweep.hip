@@ -69,6 +69,9 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #ifndef LEAN_WAVES
 #define LEAN_WAVES 8
 #endif
+#ifndef OBIA_SWEEP_GROUPS_DEFAULT
+#define OBIA_SWEEP_GROUPS_DEFAULT 1
+#endif
 #ifndef ASSIGN_WAVES
 #define ASSIGN_WAVES 6
 #endif
@@ -90,15 +93,17 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
                                                         unsigned long long *__restrict__ acc, double inv_fscale,
                                                         float *__restrict__ cent, int *__restrict__ head,
                                                         int *__restrict__ head_other,
-                                                        int total_cells, int *__restrict__ bin_stamp, int sweep_id) {
+                                                        int total_cells, int *__restrict__ bin_stamp, int sweep_id,
+                                                        int k_base, int cell_base) {
     // exit_on_fixed_point: a centroid whose record differs from the previous sweep's stamps the bin it leaves and the
     // bin it enters with the sweep number; the sweep kernel skips a tile none of whose bins was stamped since the tile
     // was last evaluated (same candidate records => same labels, same partial sums, replayed from the tile's cache).
     // the bin heads are double-buffered: while this sweep fills `head`, the buffer of the NEXT sweep is reset here
     // (saves one memset launch per sweep)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
+    // (a launch covers the centroids [k_base, total_cent) and the bins [cell_base, total_cells): one group of problems)
+    for (int i = cell_base + blockIdx.x * blockDim.x + threadIdx.x; i < total_cells; i += gridDim.x * blockDim.x) head_other[i] = -1;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = gt / G, q = gt % G;
+    const int k = k_base + gt / G, q = gt % G;
     const int lane = threadIdx.x & 63, gl0 = lane - q;       // first lane of the group inside the wave
     const bool in_range = k < total_cent;
     const int p = in_range ? cent_prob[k] : -1;
@@ -297,7 +302,7 @@ __device__ __forceinline__ void slic_assign_body(
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
-    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox) {
+    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base) {
     // COLLB (low compactness): the scoring adds a lower bound of the COLOUR term to the spatial one -- the distance of the
     // candidate's colour to the box of the footprint's features (slic.hpp: feat_boxes) -- and the visits drop from 13 to 7 per
     // footprint at compactness 0.25.  Valid because every step is monotone: |f - c| >= max(lo - c, c - hi, 0) per channel for
@@ -319,7 +324,8 @@ __device__ __forceinline__ void slic_assign_body(
 #define OBIA_XCD_GROUP 2
 #endif
     constexpr int XG = OBIA_XCD_GROUP;   // consecutive tiles that share an XCD
-    const int gtile = (((int)(blockIdx.x >> 3) / XG) * 8 + (int)(blockIdx.x & 7)) * XG + (int)(blockIdx.x >> 3) % XG;
+    // (a launch covers the tiles [tile_base, total_tiles_all) of the batch: one group of problems, see slic_run_sweeps)
+    const int gtile = tile_base + (((int)(blockIdx.x >> 3) / XG) * 8 + (int)(blockIdx.x & 7)) * XG + (int)(blockIdx.x >> 3) % XG;
     if (gtile >= total_tiles_all) return;
     STAMP_DECL
     constexpr int RS = CENT_REC + CP;
@@ -962,10 +968,10 @@ __device__ __forceinline__ void slic_assign_body(
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
-        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox
+        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base
 #define OBIA_ASSIGN_ARGS                                                                                               \
     probs, feat, mask, cent, head, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
@@ -1019,6 +1025,10 @@ __global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__
         }
 }
 
+// A group of consecutive problems of the batch whose prep / sweep chain runs on its own stream (slic_run_sweeps): the
+// centroids [k0, k1), bins [cell0, cell1) and tiles [tile0, tile1) of the batch's tables.
+struct SweepGroup { int k0, k1, cell0, cell1, tile0, tile1; hipStream_t stream; };
+
 struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; null when the option is off)
     int *bin_stamp = nullptr, *tile_lp = nullptr, *cache_k = nullptr;
     unsigned long long *cache_q = nullptr;
@@ -1027,29 +1037,30 @@ struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; 
 template <int CP>
 static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int accumulate, int accum_color, int store_labels,
                           int *orphan_flag, const FixedPointState &fp, int sweep_id, int use_cache, unsigned long long *px_counter,
-                          const KernelSpan &span) {
+                          const KernelSpan &span, const SweepGroup &sg, const int *head_cur) {
     constexpr int XGH = OBIA_XCD_GROUP;
-    dim3 grid(8 * XGH * (unsigned)(((int)b.total_tiles_all + 8 * XGH - 1) / (8 * XGH)));   // whole groups of 8 XCDs x XG tiles (see slic_assign_body)
+    if (sg.tile1 <= sg.tile0) return;
+    dim3 grid(8 * XGH * (unsigned)((sg.tile1 - sg.tile0 + 8 * XGH - 1) / (8 * XGH)));   // whole groups of 8 XCDs x XG tiles (see slic_assign_body)
     const int RQ = acc_record_qwords(CP);
     int tpp = b.probs.empty() ? 0 : b.probs[0].tiles_x * b.probs[0].tiles_y;   // tiles per problem if all problems agree, else 0
     for (auto &P : b.probs) if (P.tiles_x * P.tiles_y != tpp) tpp = 0;
 #define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, ctx->stream, span.a, span.b, 0, b.d_probs, \
-                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, \
+                       b.d_feat, b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
-                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
+                       use_cache, px_counter, b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
 #define LAUNCH_COLLB_(M)                                                                                            \
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, ctx->stream, span.a, span.b, 0, b.d_probs,   \
-                       b.d_feat, b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs,   \
+                       b.d_feat, b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
                        store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
-                       use_cache, px_counter, b.d_tile_prob, (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
+                       use_cache, px_counter, b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
 #define LAUNCH_LEAN_(M, F)                                                                                           \
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, ctx->stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
-                       b.d_mask, b.d_cent, b.d_head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
+                       b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
                        b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
-                       (int)b.total_tiles_all, orphan_flag, tpp, b.d_fbox)
+                       sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
         if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \
@@ -1114,6 +1125,49 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     for (auto &P : b.probs) if (P.H > maxh_z) maxh_z = P.H;
     if (maxh_z > 4096) maxh_z = 4096;
 
+    // Groups of problems.  The sweeps of ONE launch end with a tail (the last workgroups run on a half-empty chip), the next
+    // launch starts with a ramp (every workgroup stages its candidates before anyone computes), and between them sit two launch
+    // gaps and the small prep kernel: ~25 us per iteration that a white tile row (4 tiles, 130-us sweeps) cannot hide.  The
+    // problems of a batch never exchange anything during the sweeps, so consecutive problems are dealt into groups whose
+    // prep -> sweep chains CAN run on streams of their own (OBIA_SWEEP_GROUPS=2..4): one group's sweep fills the bubbles of the
+    // others'.  Same kernels, same arithmetic, same integer accumulators per problem: the labels do not depend on the grouping
+    // (tests/test_gpu_sweep_groups.py).  Measured on the headline workload: 2 groups +2 % (5715-5724 -> 5824-5858 Mpixel/s), 4
+    // groups -5 %: kernels that share the chip slow each other down by most of what the hidden bubbles gain (the union of the
+    // colour sweeps' run time grows from 19.3 to 20.5 ms per step), and the per-launch durations no longer mean anything -- so
+    // the default is ONE group, the option stays for batches of many small problems.
+    // Always one group when a step of the loop touches the whole batch (SLIC-zero's max-distance pass) or in the debug mode.
+    std::vector<SweepGroup> groups;
+    {
+        const char *env_groups = std::getenv("OBIA_SWEEP_GROUPS");   // (read per batch: the tests switch it inside one process)
+        int ng = (env_groups && atoi(env_groups) > 0) ? atoi(env_groups) : OBIA_SWEEP_GROUPS_DEFAULT;
+        if (ng > 1 + obia_ctx::MAX_SIDE) ng = 1 + obia_ctx::MAX_SIDE;
+        if (ng > b.nprob) ng = b.nprob;
+        if (b.slic_zero || std::getenv("OBIA_DEBUG_SYNC")) ng = 1;
+        if (ng < 1) ng = 1;
+        if (ng > 1) OBIA_TRY(side_streams(ctx, ng - 1));
+        // consecutive problems, balanced by tiles (the sweep's unit of work)
+        int p0 = 0;
+        for (int g = 0; g < ng; ++g) {
+            int p1 = p0;
+            const long long want = b.total_tiles_all * (long long)(g + 1) / ng;
+            while (p1 < b.nprob && (g == ng - 1 || (long long)b.probs[p1].tile_off + b.probs[p1].tiles_x * b.probs[p1].tiles_y <= want || p1 == p0)) ++p1;
+            if (g == ng - 1) p1 = b.nprob;
+            const bool end = p1 >= b.nprob;
+            SweepGroup sg;
+            sg.k0 = p0 < b.nprob ? b.probs[p0].cent_off : b.total_cent;
+            sg.k1 = end ? b.total_cent : b.probs[p1].cent_off;
+            sg.cell0 = p0 < b.nprob ? b.probs[p0].cell_off : b.total_cells;
+            sg.cell1 = end ? b.total_cells : b.probs[p1].cell_off;
+            sg.tile0 = p0 < b.nprob ? b.probs[p0].tile_off : (int)b.total_tiles_all;
+            sg.tile1 = end ? (int)b.total_tiles_all : b.probs[p1].tile_off;
+            sg.stream = g == 0 ? ctx->stream : ctx->side[g - 1];
+            if (p1 > p0) groups.push_back(sg);
+            p0 = p1;
+        }
+        for (size_t g = 1; g < groups.size(); ++g) groups[g].stream = ctx->side[g - 1];
+        groups[0].stream = ctx->stream;
+    }
+
     // All sweeps of the batch.  store_all = false: only the very last sweep stores its labels (the others' labels are dead
     // stores unless a valid pixel is reached by no window -- see the label stage of the sweep); true: every sweep stores, the
     // reference's literal behaviour, needed by the fixed-point replay (labels "already in place") and by SLIC-zero (its
@@ -1122,6 +1176,12 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 513, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
         debug_sync(ctx, "sweeps: memsets");
+        if (groups.size() > 1) {   // fork: the side streams start after everything queued on the context's stream so far
+            OBIA_HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));
+            for (size_t g = 1; g < groups.size(); ++g) OBIA_HIP_TRY(hipStreamWaitEvent(groups[g].stream, ctx->fork_ev, 0));
+        }
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const SweepGroup &sg = groups[gi];
         bool first = true;
         int sweep_no = 0;
         for (int pass = 0; pass < passes; ++pass) {
@@ -1133,14 +1193,15 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 ++sweep_no;   // sweep ids start at 1
                 // SLIC-zero: the per-cluster colour scale restarts at 1 with the colour pass and is carried afterwards
                 const int zmode = (b.slic_zero && !ignore_color) ? (it == 0 ? 2 : 1) : 0;
+                const long long nk = sg.k1 > sg.k0 ? sg.k1 - sg.k0 : 1;   // (at least one block: it also resets the group's bins)
                 if (RQ == 16)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv((long long)b.total_cent * 16, 256)), dim3(256), 0,
-                                       ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv(nk * 16, 256)), dim3(256), 0,
+                                       sg.stream, b.d_probs, b.d_cent_prob, sg.k1, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
+                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv((long long)b.total_cent * 32, 256)), dim3(256), 0,
-                                       ctx->stream, b.d_probs, b.d_cent_prob, b.total_cent, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, b.total_cells, fp.bin_stamp, sweep_no);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv(nk * 32, 256)), dim3(256), 0,
+                                       sg.stream, b.d_probs, b.d_cent_prob, sg.k1, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
+                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0);
                 b.d_head_cur = head_cur;
                 debug_sync(ctx, "sweeps: prep");
                 first = false;
@@ -1172,17 +1233,22 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 {
                     KernelSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);   // events bound to the dispatch
                     unsigned long long *pxc = ctx->profiling ? d_px + (ignore_color ? 256 : 0) : nullptr;
-                    if (ctx->profiling && !ignore_color && store_labels) ctx->timing.assign_store_px += (double)b.total_pix;
+                    if (gi == 0 && ctx->profiling && !ignore_color && store_labels) ctx->timing.assign_store_px += (double)b.total_pix;
                     switch (b.CP) {
-                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
-                        case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
-                        case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
-                        case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span); break;
+                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
+                        case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
+                        case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
+                        case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
                         default: set_error("bad CP"); return OBIA_E_INVALID;
                     }
                 }
                 debug_sync(ctx, ignore_color ? "sweeps: pre-pass sweep" : "sweeps: colour sweep");
             }
+        }
+        }
+        for (size_t g = 1; g < groups.size(); ++g) {   // join: whatever follows on the context's stream sees every group's labels
+            OBIA_HIP_TRY(hipEventRecord(ctx->join_ev[g - 1], groups[g].stream));
+            OBIA_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->join_ev[g - 1], 0));
         }
         OBIA_HIP_TRY(hipGetLastError());
         return OBIA_OK;
