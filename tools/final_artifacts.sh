@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-end artefacts on one GPU box: bench lines, kernel statistics of the same command, PMC passes for the traffic file.
+#   gpurun -- 'bash tools/final_artifacts.sh'   then   python tools/traffic_json.py gpurun_out/fa_fetch gpurun_out/fa_write <commit>
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 400 python bench.py > gpurun_out/fa_bench.json 2> gpurun_out/fa_bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fa_trace -- python3 bench.py --no-cpu > gpurun_out/fa_bench_rocprof.json 2> gpurun_out/fa_rocprof.err
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/fa_fetch -- python3 tools/step_trace.py > gpurun_out/fa_f.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/fa_write -- python3 tools/step_trace.py > gpurun_out/fa_w.log 2>&1
+timeout -k 10 400 python bench.py --config c4 --no-cpu --no-side > gpurun_out/fa_bench_c4.json 2> gpurun_out/fa_c4.err
+rm -f gpurun_out/fa_trace/*/*kernel_trace.csv   # (tens of MB; the statistics are what is kept)
+echo artefacts done
