@@ -265,7 +265,10 @@ int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
  * those launches, 2 = feature preparation, 3 = connectivity, 4 = zonal statistics, 5 = whole call,
  * 6 = maskSLIC spatial-only pre-pass sweeps (ms), 7 = pixels actually processed by the launches of 0
  * (sum; tiles skipped by exit_on_fixed_point are not counted), 8 = the same for the pre-pass launches,
- * 9 = pixels of the launches of 0 that also stored their labels (only the last sweep of a batch does).
+ * 9 = pixels of the launches of 0 that also stored their labels (only the last sweep of a batch does),
+ * 10 / 11 = time during which at least one colour / pre-pass sweep was running (equals 0 / 6 unless the batch's problems run
+ * as groups on side streams, OBIA_SWEEP_GROUPS).  The events of a sweep are bound to its dispatch (hipExtLaunchKernelGGL): 0 and
+ * 6 are sums of the kernels' own start-to-end times, as a rocprofv3 kernel trace reports them.
  * `enabled`: 0 off, 1 every class, 2 only the colour sweeps (an event pair costs ~2.5 us of stream time: with all classes on,
  * a step of the headline workload records ~420 pairs = 1.1 ms; bench.py times its steps in mode 2).                       */
 int obia_set_profiling(obia_ctx *ctx, int enabled);
