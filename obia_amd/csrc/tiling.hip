@@ -66,11 +66,44 @@ __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *_
 
 // step 2: dense tile mask.  black: the input mask.  white: input mask minus kept (overlapping) segments
 // minus the corner squares; segments within the polygon are erased from G (they will be re-segmented).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restrict__ wins, const uint8_t *__restrict__ inmask,
                                                         int32_t *__restrict__ G, int Wr, int white,
                                                         const unsigned *__restrict__ inside, const unsigned *__restrict__ seg_size,
                                                         uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask) {
     const TileWin t = wins[blockIdx.y];
+    // one pixel of the tile: its mask byte given the input mask byte and the global label under it
+    auto decide = [&](int y, int x, long long gp, uint8_t m, int g) -> uint8_t {
+        if (!white) return m;
+        if (in_corner(t, y, x)) return 0;
+        if (g > 0) {
+            if (inside[g] == seg_size[g]) { G[gp] = 0; alive[g] = 0; }   // within: dropped
+            else m = 0;                                                    // overlaps: kept, masked out
+        }
+        return m;
+    };
+    if (VEC4) {
+        // four consecutive pixels per lane: one dword of mask bytes, one int4 of labels, one dword stored (the host checks that
+        // every window's x0, w and pix_off and the row pitch are multiples of four and the base pointers aligned)
+        const int w4 = t.w >> 2;
+        for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+            for (int x4 = threadIdx.x; x4 < w4; x4 += 256) {
+                const int x = 4 * x4;
+                const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
+                const unsigned mw = inmask ? *reinterpret_cast<const unsigned *>(inmask + gp) : 0x01010101u;
+                int4 g = make_int4(0, 0, 0, 0);
+                if (white) g = *reinterpret_cast<const int4 *>(G + gp);
+                const int gv[4] = {g.x, g.y, g.z, g.w};
+                unsigned out = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint8_t m = ((mw >> (8 * u)) & 0xffu) != 0;
+                    out |= (unsigned)decide(y, x + u, gp + u, m, gv[u]) << (8 * u);
+                }
+                *reinterpret_cast<unsigned *>(dmask + t.pix_off + (long long)y * t.w + x) = out;
+            }
+        return;
+    }
     for (int y = blockIdx.x; y < t.h; y += gridDim.x)
     for (int x0 = threadIdx.x; x0 < t.w; x0 += 4 * 256) {   // four pixels in flight per lane
         uint8_t mv[4];
@@ -90,18 +123,7 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
             const int x = x0 + 256 * u;
             if (x >= t.w) continue;
             const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
-            uint8_t m = mv[u];
-            if (white) {
-                if (in_corner(t, y, x)) m = 0;
-                else {
-                    const int g = gv[u];
-                    if (g > 0) {
-                        if (inside[g] == seg_size[g]) { G[gp] = 0; alive[g] = 0; }   // within: dropped
-                        else m = 0;                                                    // overlaps: kept, masked out
-                    }
-                }
-            }
-            dmask[t.pix_off + (long long)y * t.w + x] = m;
+            dmask[t.pix_off + (long long)y * t.w + x] = decide(y, x, gp, mv[u], gv[u]);
         }
     }
 }
@@ -345,8 +367,17 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         OBIA_HIP_TRY(hipMemsetAsync(S.inside, 0, sizeof(unsigned) * (size_t)S.next_id, ctx->stream));
         hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
     }
-    hipLaunchKernelGGL(tile_mask_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask, S.G, S.W,
-                       white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+    {
+        bool vec4 = (S.W % 4 == 0) && (reinterpret_cast<uintptr_t>(S.inmask) % 4 == 0) && (reinterpret_cast<uintptr_t>(S.G) % 16 == 0) &&
+                    (reinterpret_cast<uintptr_t>(b.d_mask) % 4 == 0);
+        for (auto &t : wins) vec4 = vec4 && (t.x0 % 4 == 0) && (t.w % 4 == 0) && (t.pix_off % 4 == 0);
+        if (vec4)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<true>), dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
+                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<false>), dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
+                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+    }
     // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
     std::vector<int> skip;
     const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
