@@ -1145,27 +1145,26 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         if (b.slic_zero || std::getenv("OBIA_DEBUG_SYNC")) ng = 1;
         if (ng < 1) ng = 1;
         if (ng > 1) OBIA_TRY(side_streams(ctx, ng - 1));
-        // consecutive problems, balanced by tiles (the sweep's unit of work)
-        int p0 = 0;
-        for (int g = 0; g < ng; ++g) {
-            int p1 = p0;
-            const long long want = b.total_tiles_all * (long long)(g + 1) / ng;
-            while (p1 < b.nprob && (g == ng - 1 || (long long)b.probs[p1].tile_off + b.probs[p1].tiles_x * b.probs[p1].tiles_y <= want || p1 == p0)) ++p1;
-            if (g == ng - 1) p1 = b.nprob;
-            const bool end = p1 >= b.nprob;
-            SweepGroup sg;
-            sg.k0 = p0 < b.nprob ? b.probs[p0].cent_off : b.total_cent;
-            sg.k1 = end ? b.total_cent : b.probs[p1].cent_off;
-            sg.cell0 = p0 < b.nprob ? b.probs[p0].cell_off : b.total_cells;
-            sg.cell1 = end ? b.total_cells : b.probs[p1].cell_off;
-            sg.tile0 = p0 < b.nprob ? b.probs[p0].tile_off : (int)b.total_tiles_all;
-            sg.tile1 = end ? (int)b.total_tiles_all : b.probs[p1].tile_off;
-            sg.stream = g == 0 ? ctx->stream : ctx->side[g - 1];
-            if (p1 > p0) groups.push_back(sg);
-            p0 = p1;
+        // consecutive problems, balanced by tiles (the sweep's unit of work): group g starts at the first problem whose first tile
+        // lies at or beyond g / ng of the batch's tiles
+        std::vector<int> cut(1, 0);
+        for (int g = 1; g < ng; ++g) {
+            const long long want = b.total_tiles_all * (long long)g / ng;
+            int p = cut.back();
+            while (p < b.nprob && b.probs[p].tile_off < want) ++p;
+            if (p > cut.back() && p < b.nprob) cut.push_back(p);
         }
-        for (size_t g = 1; g < groups.size(); ++g) groups[g].stream = ctx->side[g - 1];
-        groups[0].stream = ctx->stream;
+        cut.push_back(b.nprob);
+        for (size_t g = 0; g + 1 < cut.size(); ++g) {
+            const SlicProblem &P0 = b.probs[cut[g]];
+            const bool last = cut[g + 1] >= b.nprob;
+            SweepGroup sg;
+            sg.k0 = P0.cent_off;   sg.k1 = last ? b.total_cent : b.probs[cut[g + 1]].cent_off;
+            sg.cell0 = P0.cell_off; sg.cell1 = last ? b.total_cells : b.probs[cut[g + 1]].cell_off;
+            sg.tile0 = P0.tile_off; sg.tile1 = last ? (int)b.total_tiles_all : b.probs[cut[g + 1]].tile_off;
+            sg.stream = g == 0 ? ctx->stream : ctx->side[g - 1];
+            groups.push_back(sg);
+        }
     }
 
     // All sweeps of the batch.  store_all = false: only the very last sweep stores its labels (the others' labels are dead
