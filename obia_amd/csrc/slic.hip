@@ -271,12 +271,15 @@ __global__ __launch_bounds__(256) void features_kernel(const float *__restrict__
 // The same arithmetic, written as quad-row blocks (slic.hpp: feat_block_f4): a thread owns the four pixels
 // (4q .. 4q+3, x), reads them row by row (each row coalesced across the wave) and writes one float4 per channel
 // (sixteen consecutive threads -> 256 contiguous bytes of a channel run).  Blocks walk quad rows.
-template <int CP>
+// BOX: the colour boxes of the sweep's footprints (slic.hpp: feat_boxes; low compactness only) come out of the same pass -- a
+// block then walks footprint bands (four quad rows), a thread keeps the lo / hi of its column over the band and the sixteen
+// lanes of a footprint fold them by shuffles: no second pass over the planes (it cost 1.6 ms per step at C3).
+template <int CP, bool BOX>
 __global__ __launch_bounds__(256) void features_planes_kernel(const float *__restrict__ src, int Ws, int C,
                                                               const SrcWindow *__restrict__ wins,
                                                               const unsigned *__restrict__ keys, int normalize,
                                                               int to_lab, float ratio, float *__restrict__ feat,
-                                                              unsigned *__restrict__ maxabs_bits) {
+                                                              unsigned *__restrict__ maxabs_bits, float *__restrict__ fbox) {
     const int p = blockIdx.y;
     const SrcWindow wdw = wins[p];
     float bmn[CP], bden[CP];
@@ -285,9 +288,8 @@ __global__ __launch_bounds__(256) void features_planes_kernel(const float *__res
     float local_max = 0.0f;
     const int QH = (wdw.h + 3) >> 2, XB = (wdw.w + 15) >> 4;
     float4 *__restrict__ planes = reinterpret_cast<float4 *>(feat) + wdw.feat_off;
-    for (int q = blockIdx.x; q < QH; q += gridDim.x)
-    for (int x = threadIdx.x; x < 16 * XB; x += blockDim.x) {
-        float v[4][CP];
+    // one quad row of one column: features of the four pixels, stored as one float4 per channel
+    auto quad = [&](int q, int x, float (&v)[4][CP]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = 4 * q + i;
@@ -302,64 +304,49 @@ __global__ __launch_bounds__(256) void features_planes_kernel(const float *__res
         float4 *dst = planes + ((long long)q * XB + (x >> 4)) * (CP * 16) + (x & 15);
 #pragma unroll
         for (int c = 0; c < CP; ++c) dst[c * 16] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+    };
+    if (!BOX) {
+        for (int q = blockIdx.x; q < QH; q += gridDim.x)
+            for (int x = threadIdx.x; x < 16 * XB; x += blockDim.x) {
+                float v[4][CP];
+                quad(q, x, v);
+            }
+    } else {
+        const int FH = (QH + 3) >> 2;   // footprint bands
+        for (int fy = blockIdx.x; fy < FH; fy += gridDim.x)
+            for (int x = threadIdx.x; x < 16 * XB; x += blockDim.x) {   // (whole 16-lane groups: 16 * XB is a multiple of 16)
+                float lo[CP], hi[CP];
+#pragma unroll
+                for (int c = 0; c < CP; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int q = 4 * fy + qq;
+                    if (q >= QH) break;   // block-uniform
+                    float v[4][CP];
+                    quad(q, x, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * q + i < wdw.h && x < wdw.w) {   // pixels outside the window are left out of the box
+#pragma unroll
+                            for (int c = 0; c < CP; ++c) { lo[c] = fminf(lo[c], v[i][c]); hi[c] = fmaxf(hi[c], v[i][c]); }
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < CP; ++c)
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) {
+                        lo[c] = fminf(lo[c], __shfl_xor(lo[c], off));
+                        hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off));
+                    }
+                if ((x & 15) == 0) {
+                    float *o = fbox + (wdw.fb_off + (long long)fy * XB + (x >> 4)) * (2 * CP);
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) { o[c] = lo[c]; o[CP + c] = hi[c]; }
+                }
+            }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
     if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits + p, __float_as_uint(local_max));
-}
-
-// Colour boxes of the sweep's footprints (slic.hpp: feat_boxes): one wave per footprint, a lane reads what it reads in the sweep
-// (one float4 per channel = its four pixels), pixels outside the window are left out; lo / hi over the wave by shuffles.
-template <int CP>
-__global__ __launch_bounds__(256) void feat_box_kernel(const float4 *__restrict__ feat4, const SrcWindow *__restrict__ wins,
-                                                       float *__restrict__ fbox) {
-    const SrcWindow wdw = wins[blockIdx.y];
-    const int XB = (wdw.w + 15) >> 4, QH = (wdw.h + 3) >> 2;
-    const long long nbox = (long long)((QH + 3) >> 2) * XB;
-    const int lane = threadIdx.x & 63;
-    for (long long fi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); fi < nbox; fi += (long long)gridDim.x * 4) {
-        const int fyi = (int)(fi / XB), fxi = (int)(fi - (long long)fyi * XB);
-        const int q = 4 * fyi + (lane >> 4), x = 16 * fxi + (lane & 15);
-        const bool in = (q < QH) && (x < wdw.w);
-        const float4 *src = feat4 + wdw.feat_off + ((long long)(in ? q : 0) * XB + fxi) * (CP * 16) + (lane & 15);
-        float lo[CP], hi[CP];
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            const float4 t = src[c * 16];
-            const float v[4] = {t.x, t.y, t.z, t.w};
-            lo[c] = INFINITY; hi[c] = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (in && 4 * q + r < wdw.h) { lo[c] = fminf(lo[c], v[r]); hi[c] = fmaxf(hi[c], v[r]); }
-        }
-#pragma unroll
-        for (int c = 0; c < CP; ++c)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo[c] = fminf(lo[c], __shfl_xor(lo[c], off));
-                hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off));
-            }
-        if (lane == 0) {
-            float *o = fbox + (wdw.fb_off + fi) * (2 * CP);
-#pragma unroll
-            for (int c = 0; c < CP; ++c) { o[c] = lo[c]; o[CP + c] = hi[c]; }
-        }
-    }
-}
-
-void slic_feature_boxes_launch(hipStream_t stream, int CP, int np, const SrcWindow *d_windows, long long max_boxes, const float *d_feat,
-                               float *d_fbox) {
-    long long gx = (max_boxes + 3) / 4;
-    if (gx > 65535) gx = 65535;
-    if (gx < 1) gx = 1;
-    dim3 grid((unsigned)gx, np);
-    const float4 *f4 = reinterpret_cast<const float4 *>(d_feat);
-    switch (CP) {
-        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(feat_box_kernel<4>), grid, dim3(256), 0, stream, f4, d_windows, d_fbox); break;
-        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(feat_box_kernel<8>), grid, dim3(256), 0, stream, f4, d_windows, d_fbox); break;
-        case 12: hipLaunchKernelGGL(HIP_KERNEL_NAME(feat_box_kernel<12>), grid, dim3(256), 0, stream, f4, d_windows, d_fbox); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(feat_box_kernel<16>), grid, dim3(256), 0, stream, f4, d_windows, d_fbox); break;
-    }
 }
 
 // The colour-box bound pays when the colour term decides (image ratio = 1 / compactness large): measured break-even near
@@ -378,7 +365,7 @@ __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
 // Launch half of the feature pass on `stream`: min / max of every band of every window, then the features.
 // d_keys layout for np windows: keys[np][C][2] (min, max as ordered uints) | nonfinite[np] | max|feature| bits [np].
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
-                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes) {
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes, float *d_fbox) {
     if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
     const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + 2 * (size_t)np;
     unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
@@ -394,12 +381,15 @@ int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWin
             hipLaunchKernelGGL(HIP_KERNEL_NAME(band_minmax_kernel<1>), dim3(gx, np), dim3(FP_NT), 0, stream, src, Ws, C, d_windows,
                                d_keys, (int *)d_nonfinite);
     }
-    const int rows = planes ? (maxh + 3) / 4 : maxh;
+    const bool box = planes && d_fbox != nullptr;   // colour boxes from the same pass (a block walks footprint bands of 16 rows)
+    const int rows = box ? (maxh + 15) / 16 : (planes ? (maxh + 3) / 4 : maxh);
     dim3 grid(rows < 4096 ? rows : 4096, np);
 #define LAUNCH_FEAT(CPV)                                                                                                  \
     do {                                                                                                                  \
-        if (planes) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, \
-                                       d_windows, d_keys, normalize, to_lab, ratio, d_feat, d_maxabs);                    \
+        if (box) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV, true>), grid, dim3(256), 0, stream, src, Ws, C, \
+                                    d_windows, d_keys, normalize, to_lab, ratio, d_feat, d_maxabs, d_fbox);               \
+        else if (planes) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV, false>), grid, dim3(256), 0, stream, src, Ws, C, \
+                                       d_windows, d_keys, normalize, to_lab, ratio, d_feat, d_maxabs, (float *)nullptr);  \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, d_windows,  \
                                 d_keys, normalize, to_lab, ratio, d_feat, d_maxabs);                                      \
     } while (0)
@@ -472,12 +462,7 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     int maxh = 1;
     for (auto &w : b.windows) if (w.h > maxh) maxh = w.h;
     OBIA_TRY(slic_features_launch(ctx->stream, C, b.CP, np, b.d_windows, maxh, src, Ws, normalize, to_lab, ratio, b.d_feat, d_keys,
-                                  b.feat_planes));
-    if (b.col_lb && b.d_fbox && b.feat_planes) {
-        long long mb = 1;
-        for (auto &w : b.windows) mb = std::max(mb, feat_boxes(w.h, w.w));
-        slic_feature_boxes_launch(ctx->stream, b.CP, np, b.d_windows, mb, b.d_feat, b.d_fbox);
-    }
+                                  b.feat_planes, (b.col_lb && b.feat_planes) ? b.d_fbox : nullptr));
     // one read-back: min/max keys (constant-band check), non-finite flags, max|feature| per window
     std::vector<unsigned> host(ntot);
     OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));

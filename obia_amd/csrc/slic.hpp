@@ -100,14 +100,12 @@ struct SlicBatch {
 // skip[p] = 1 (its features are zero) instead of failing the whole batch -- the reference's tiler
 // swallows the per-tile ValueError (tiling.py:149-150).
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
-                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes = true);
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes = true,
+                         float *d_fbox = nullptr);   // d_fbox (plane layout only): the footprints' colour boxes from the same pass
 int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *nonfinite, const unsigned *maxabs_bits, int normalize,
                          std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
                           int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
-// Colour boxes of every footprint of `np` windows whose features lie in d_feat (plane layout): launch only.
-void slic_feature_boxes_launch(hipStream_t stream, int CP, int np, const SrcWindow *d_windows, long long max_boxes, const float *d_feat,
-                               float *d_fbox);
 // Does a batch with this image ratio (1 / compactness) use the colour-box bound?  (OBIA_COLOUR_BOUND=0/1 overrides.)
 bool slic_use_colour_bound(float ratio);
 

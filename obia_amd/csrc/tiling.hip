@@ -559,12 +559,7 @@ static int prefetch_white_launch(obia_ctx *ctx, TileState &S) {
     OBIA_TRY(upload_async(ctx, pf.d_windows, pf.windows.data(), sizeof(SrcWindow) * NP));
     const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
     OBIA_TRY(slic_features_launch(ctx->stream, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
-                                  (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys));
-    if (pf.d_fbox) {
-        long long mb = 1;
-        for (auto &w : pf.windows) mb = std::max(mb, feat_boxes(w.h, w.w));
-        slic_feature_boxes_launch(ctx->stream, CP, (int)NP, pf.d_windows, mb, pf.d_feat, pf.d_fbox);
-    }
+                                  (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys, true, pf.d_fbox));
     return OBIA_OK;
 }
 
