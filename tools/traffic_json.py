@@ -27,7 +27,7 @@ black_px = sum(T * T for tj in range(nt) for ti in range(nt) if (ti + tj) % 2 ==
 white_px = sum(win(tj) * win(ti) for tj in range(nt) for ti in range(nt) if (ti + tj) % 2 == 1)
 px_per_launch = (black_px + white_px) / (1 + nt)               # one black batch + one batch per white tile row
 names = {"slic_assign_colour": "slic_assign_kernel<8, true, false, false, false>", "slic_prepass": "slic_prepass_kernel<8, true, false>",
-         "features": "features_planes_kernel<8>", "band_minmax": "band_minmax_kernel<4>", "zonal": "zonal_kernel<8>"}
+         "features": "features_planes_kernel<8,", "band_minmax": "band_minmax_kernel<4>", "zonal": "zonal_kernel<8>"}
 out = {"commit": commit, "kernel_source_sha256": kernel_source_sha256(),
        "workload": {"size": S, "tile": T, "buffer": B, "bands": C, "compactness": 10.0},
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/step_trace.py; bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, mean over dispatches",
