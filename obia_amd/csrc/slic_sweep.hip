@@ -294,7 +294,10 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 // K2: the sweep.  grid = (max tiles per problem, nprob).
 // LEAN: a spatial-only pre-pass sweep that folds no colours (nine of the ten pre-pass sweeps): no feature registers, no
 // colour scratch in LDS -- the same code with those parts compiled out, launched at a higher occupancy.
-template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN, bool COLLB>
+// NCH: the channels that exist (C <= CP).  Planes, records and accumulators come in groups of four channels; the padded ones
+// hold zeros in the features and in every centroid, so a body compiled with NCH < CP neither loads them nor adds their
+// (0 - 0)^2 = +0 to the colour distance: same bits, a quarter less traffic and colour arithmetic for 9 bands run as 12.
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN, bool COLLB, int NCH = CP>
 __device__ __forceinline__ void slic_assign_body(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
     const float *__restrict__ cent, const int *__restrict__ head,
@@ -424,6 +427,7 @@ __device__ __forceinline__ void slic_assign_body(
                                      ? ((unsigned)(lane_o >> 4) * (unsigned)((LEAN ? 0 : CP) * 16 * P.XB) + (unsigned)(lane_o & 15)) * 16u : 0u;
 #pragma unroll
             for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) {
+                if (ch >= NCH) { f2[ch][0] = splat(0.0f); f2[ch][1] = splat(0.0f); continue; }   // padded channel: zeros, not read
                 const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pb + ch * 16) + (size_t)fob);
                 f2[ch][0] = (v2f){t.x, t.y};
                 f2[ch][1] = (v2f){t.z, t.w};
@@ -716,7 +720,7 @@ __device__ __forceinline__ void slic_assign_body(
                 float col[LEAN ? 1 : CP];
                 if (!IGNORE_COLOR) {
 #pragma unroll
-                    for (int q = 0; q < CP / 4; ++q) {
+                    for (int q = 0; q < (NCH + 3) / 4; ++q) {
                         const float4 t = crec[2 + q];   // wave-uniform address: scalar loads, the colours stay in SGPRs
                         col[4 * q] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
                     }
@@ -730,7 +734,7 @@ __device__ __forceinline__ void slic_assign_body(
                     v2f t0 = f2[0][0] - splat(col[0]), t1 = f2[0][1] - splat(col[0]);
                     v2f dc0 = t0 * t0, dc1 = t1 * t1;
 #pragma unroll
-                    for (int ch = 1; ch < (LEAN ? 1 : CP); ++ch) {
+                    for (int ch = 1; ch < (LEAN ? 1 : NCH); ++ch) {   // (channels >= NCH: 0 - 0, squared, added: +0)
                         t0 = f2[LEAN ? 0 : ch][0] - splat(col[LEAN ? 0 : ch]);
                         t1 = f2[LEAN ? 0 : ch][1] - splat(col[LEAN ? 0 : ch]);
                         dc0 += t0 * t0;
@@ -844,7 +848,7 @@ __device__ __forceinline__ void slic_assign_body(
                     pw += 1u | ((unsigned)(yb_i + j - ty0) << 8) | (xrel << 20);
                     if (!LEAN && accum_color) {
 #pragma unroll
-                        for (int ch = 0; ch < CP; ++ch) rf[LEAN ? 0 : ch] += to_fixed32((j & 1) ? f2[LEAN ? 0 : ch][j >> 1].y : f2[LEAN ? 0 : ch][j >> 1].x, fs);
+                        for (int ch = 0; ch < NCH; ++ch) rf[LEAN ? 0 : ch] += to_fixed32((j & 1) ? f2[LEAN ? 0 : ch][j >> 1].y : f2[LEAN ? 0 : ch][j >> 1].x, fs);   // (padded channels stay 0)
                     }
                 }
             }
@@ -974,15 +978,15 @@ __device__ __forceinline__ void slic_assign_body(
         cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base
 
 // the colour sweeps and the last pre-pass sweep
-template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO>
+template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, int NCH = CP>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ASSIGN_WAVES, ASSIGN_WAVES))) void slic_assign_kernel(OBIA_ASSIGN_PARAMS) {
-    slic_assign_body<CP, MASKED, IGNORE_COLOR, FIXPT, SLICZERO, false, false>(OBIA_ASSIGN_ARGS);
+    slic_assign_body<CP, MASKED, IGNORE_COLOR, FIXPT, SLICZERO, false, false, NCH>(OBIA_ASSIGN_ARGS);
 }
 
 // the colour sweeps at low compactness: with the colour-box bound (one more LDS table, a few more registers)
-template <int CP, bool MASKED>
+template <int CP, bool MASKED, int NCH = CP>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void slic_assign_collb_kernel(OBIA_ASSIGN_PARAMS) {
-    slic_assign_body<CP, MASKED, false, false, false, false, true>(OBIA_ASSIGN_ARGS);
+    slic_assign_body<CP, MASKED, false, false, false, false, true, NCH>(OBIA_ASSIGN_ARGS);
 }
 
 // the pre-pass sweeps that fold no colours: no feature registers, 4 KB of LDS
@@ -1044,29 +1048,39 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     const int RQ = acc_record_qwords(CP);
     int tpp = b.probs.empty() ? 0 : b.probs[0].tiles_x * b.probs[0].tiles_y;   // tiles per problem if all problems agree, else 0
     for (auto &P : b.probs) if (P.tiles_x * P.tiles_y != tpp) tpp = 0;
-#define LAUNCH_ASSIGN_(M, I, F, Z)                                                                                   \
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_kernel<CP, M, I, F, Z>), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, \
-                       b.d_feat, b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
-                       store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
-                       use_cache, px_counter, b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
+#define LAUNCH_K_(...)                                                                                               \
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(__VA_ARGS__), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
+                          b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels, b.start_label,      \
+                          b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter,          \
+                          b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
+    // channels that exist: C of the CP = 4 * ceil(C / 4) the planes and records hold.  The two kernels that run 9 of every 10
+    // sweeps come in a variant per padding (slic_assign_body: NCH); the others treat the padded channels like real ones.
+    const int pad = CP - b.C;
+#define LAUNCH_ASSIGN_(M, I, F, Z) LAUNCH_K_(slic_assign_kernel<CP, M, I, F, Z>)
+#define LAUNCH_MAIN_(M)                                                                                              \
+    do {                                                                                                             \
+        if (pad == 1) LAUNCH_K_(slic_assign_kernel<CP, M, false, false, false, CP - 1>);                             \
+        else if (pad == 2) LAUNCH_K_(slic_assign_kernel<CP, M, false, false, false, CP - 2>);                        \
+        else if (pad == 3) LAUNCH_K_(slic_assign_kernel<CP, M, false, false, false, CP - 3>);                        \
+        else LAUNCH_K_(slic_assign_kernel<CP, M, false, false, false>);                                              \
+    } while (0)
     // SLIC-zero only changes the colour sweeps (the spatial pre-pass computes no colour term) and is not combined with
     // the fixed-point cache (the per-cluster scale changes after the records were compared)
-#define LAUNCH_COLLB_(M)                                                                                            \
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_assign_collb_kernel<CP, M>), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs,   \
-                       b.d_feat, b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate,       \
-                       store_labels, b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id,  \
-                       use_cache, px_counter, b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
-#define LAUNCH_LEAN_(M, F)                                                                                           \
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(slic_prepass_kernel<CP, M, F>), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
-                       b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels,          \
-                       b.start_label, b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter, b.d_tile_prob,           \
-                       sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
+#define LAUNCH_COLLB_(M)                                                                                             \
+    do {                                                                                                             \
+        if (pad == 1) LAUNCH_K_(slic_assign_collb_kernel<CP, M, CP - 1>);                                            \
+        else if (pad == 2) LAUNCH_K_(slic_assign_collb_kernel<CP, M, CP - 2>);                                       \
+        else if (pad == 3) LAUNCH_K_(slic_assign_collb_kernel<CP, M, CP - 3>);                                       \
+        else LAUNCH_K_(slic_assign_collb_kernel<CP, M>);                                                             \
+    } while (0)
+#define LAUNCH_LEAN_(M, F) LAUNCH_K_(slic_prepass_kernel<CP, M, F>)
 #define LAUNCH_ASSIGN(M, I)                                                                                          \
     do {                                                                                                             \
         if ((I) && !accum_color) { if (fp.bin_stamp) LAUNCH_LEAN_(M, true); else LAUNCH_LEAN_(M, false); }           \
         else if (b.slic_zero && !(I)) LAUNCH_ASSIGN_(M, false, false, true);                                         \
         else if (fp.bin_stamp) LAUNCH_ASSIGN_(M, I, true, false);                                                    \
         else if (b.col_lb && b.d_fbox && !(I)) LAUNCH_COLLB_(M);                                                     \
+        else if (!(I)) LAUNCH_MAIN_(M);                                                                              \
         else LAUNCH_ASSIGN_(M, I, false, false);                                                                     \
     } while (0)
     if (b.masked) { if (ignore_color) LAUNCH_ASSIGN(true, true); else LAUNCH_ASSIGN(true, false); }
@@ -1075,6 +1089,8 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
 #undef LAUNCH_ASSIGN_
 #undef LAUNCH_LEAN_
 #undef LAUNCH_COLLB_
+#undef LAUNCH_MAIN_
+#undef LAUNCH_K_
 }
 
 __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
