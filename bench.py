@@ -20,7 +20,7 @@ Side legs at N = 1 (never `value`; --no-side skips them): the same workload at c
 notebooks/deepfor.ipynb:402 -- at compactness 10 on [0,1] features the result is nearly a grid), and BASELINE configs[4]
 (8192 x 8192 x 3 quickshift, kernel_size 5, max_dist 10).
 
-The JSON line carries `roofline` (dominant kernel = the SLIC colour sweep slic_assign_kernel<8,true,false>:
+The JSON line carries `roofline` (dominant kernel = the SLIC colour sweep slic_assign_kernel<8,true,false,false,false,8>:
 algorithmic bytes (4*C + 4 = 36 B/pixel) x pixels per launch / launch time from HIP events on
 the library's stream) and `cpu_baseline` (the C oracle -- a port, 1 thread -- on one 2048^2 tile of the same
 workload).
@@ -139,8 +139,8 @@ def cpu_baseline(C, tile, buffer_, crown_radius, pixel, compactness):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=16384, help="raster side at N=1 (default: BASELINE configs[2])")
     ap.add_argument("--tile", type=int, default=2048)
     ap.add_argument("--buffer", type=int, default=64)
@@ -365,7 +365,7 @@ def main():
             "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,
                        "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
                        "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu"},
-            "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false>",
+            "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false,{C}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,

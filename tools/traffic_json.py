@@ -26,7 +26,7 @@ win = lambda i: min(S, i * T + T + B) - max(0, i * T - B)      # noqa: E731
 black_px = sum(T * T for tj in range(nt) for ti in range(nt) if (ti + tj) % 2 == 0)
 white_px = sum(win(tj) * win(ti) for tj in range(nt) for ti in range(nt) if (ti + tj) % 2 == 1)
 px_per_launch = (black_px + white_px) / (1 + nt)               # one black batch + one batch per white tile row
-names = {"slic_assign_colour": "slic_assign_kernel<8, true, false, false, false>", "slic_prepass": "slic_prepass_kernel<8, true, false>",
+names = {"slic_assign_colour": "slic_assign_kernel<8, true, false, false, false", "slic_prepass": "slic_prepass_kernel<8, true, false>",
          "features": "features_planes_kernel<8,", "band_minmax": "band_minmax_kernel<4>", "zonal": "zonal_kernel<8>"}
 out = {"commit": commit, "kernel_source_sha256": kernel_source_sha256(),
        "workload": {"size": S, "tile": T, "buffer": B, "bands": C, "compactness": 10.0},
