@@ -518,7 +518,7 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
 // neighbour (settle < start; a small component that finds none is written back as 0 == unset when
 // start_label is 1).  Returns the last labelled neighbour met.
 __device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict__ newlab,
-                          const int *__restrict__ settle, int r, int start, int mark, int H, int W, int base,
+                          const int *settle, int r, int start, int mark, int H, int W, int base,
                           int *__restrict__ q, int32_t *__restrict__ out, int *n_out) {
     int head = 0, tail = 1, adjacent = -1;
     q[0] = start;
@@ -550,24 +550,33 @@ __device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict_
 // labelled neighbour is found and start_label is 1 the component is written back as 0 (== unset), the
 // raster scan meets it again at its next pixel and the BFS is replayed from there.  settle_out[s] = start
 // pixel of the attempt that found a neighbour (INT_MAX if none), target[s] = that neighbour pixel.
-// `out` doubles as the visited map (rewritten by the final relabel pass).  Rounds are Jacobi iterations
-// on `settle` (small components adjacent to other small components); *changed reports progress.
+// `out` doubles as the visited map (rewritten by the final relabel pass).
+// The settle times are the least fixed point of a monotone map (a neighbour that settles later can only make this component
+// settle later), iterated IN PLACE from the optimistic start: a round evaluates a work list -- every small component in round 0,
+// afterwards the small neighbours of the components whose settle time moved in the round before (a component meets all its
+// neighbours in its own BFS, adjacency is symmetric, so the one that moves enqueues those that depend on it; `tag` keeps a
+// component from being enqueued twice in a round).  Reads of a neighbour's time may be stale inside a round: every value read
+// lies between the start and the fixed point, a component whose neighbour moved is evaluated again in the next round on values
+// at least as new as the end of this one, and the rounds end when nothing moved -- the same fixed point as synchronous (Jacobi)
+// rounds over all components, at the cost of the frontier instead of the whole list per round.
 __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__restrict__ probs, int nprob,
                                                           const int *__restrict__ parent, const int *__restrict__ newlab,
                                                           const int *__restrict__ small_list, const int *__restrict__ small_qoff,
-                                                          int n_small, int start_label,
-                                                          const int *__restrict__ settle_in, int *__restrict__ settle_out,
+                                                          int start_label, int *__restrict__ settle,
                                                           int *__restrict__ queue, int32_t *__restrict__ out,
-                                                          int *__restrict__ target, int *__restrict__ changed) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_small) return;
+                                                          int *__restrict__ target, const int *__restrict__ work_in, int n_items,
+                                                          int *__restrict__ work_out, int *__restrict__ work_cnt,
+                                                          int *__restrict__ tag, int round) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const int s = work_in ? work_in[i] : i;
     const int r = small_list[s];
     const CcProblem P = probs[find_prob(probs, nprob, r)];
     const int H = P.H, W = P.W, base = (int)P.pix_off;
     int *q = queue + small_qoff[s];
     int csize = 0;
     int start = r;
-    int adjacent = replay_bfs(parent, newlab, settle_in, r, r, -(s + 2), H, W, base, q, out, &csize);
+    int adjacent = replay_bfs(parent, newlab, settle, r, r, -(s + 2), H, W, base, q, out, &csize);
     if (adjacent < 0 && start_label == 1) {
         start = 0x7fffffff;
         for (int a = 1; a < csize && adjacent < 0; ++a) {
@@ -580,14 +589,31 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__res
             const int st = q[a];
             for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the last attempt
             int n2 = 0;
-            adjacent = replay_bfs(parent, newlab, settle_in, r, st, -(s + 2), H, W, base, q, out, &n2);
+            adjacent = replay_bfs(parent, newlab, settle, r, st, -(s + 2), H, W, base, q, out, &n2);
             if (adjacent >= 0) start = st;
         }
     }
     for (int i = 0; i < csize; ++i) out[q[i]] = 0;
     target[s] = adjacent;
-    settle_out[s] = start;
-    if (settle_in[s] != start) atomicOr(changed, 1);
+    if (settle[s] == start) return;
+    settle[s] = start;
+    // moved: the small components around this one (q holds its pixels) are evaluated again in the next round
+    for (int i = 0; i < csize; ++i) {
+        const int p = q[i];
+        const int y = (p - base) / W, x = (p - base) - y * W;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
+            const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const int rn = parent[base + yy * W + xx];
+            if (rn < 0 || rn == r) continue;
+            const int nl = newlab[rn];
+            if (nl >= 0) continue;
+            const int t = -nl - 2;
+            if (atomicExch(&tag[t], round + 1) != round + 1) work_out[atomicAdd(work_cnt, 1)] = t;
+        }
+    }
 }
 
 __global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_small, int *__restrict__ settle) {
@@ -695,27 +721,32 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
                            newlab, small_list, small_qoff, counters, rb);
     if (n_small > 0) {
-        int *settle_a = A.get<int>(n_small), *settle_b = A.get<int>(n_small);
-        if (!settle_a || !settle_b) return OBIA_E_NOMEM;
+        int *settle = A.get<int>(n_small), *work_a = A.get<int>(n_small), *work_b = A.get<int>(n_small), *tag = A.get<int>(n_small);
+        if (!settle || !work_a || !work_b || !tag) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
-        hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle_a);
-        // optimistic start (every small component labelled at its first pixel), then Jacobi rounds until the
-        // settle times stop moving; one round settles everything unless small components that find no
-        // labelled neighbour touch each other
-        // (settle times only move forward, and a component's settle time is one of its own pixels or "never": the rounds end
-        // after at most small_px + 1 of them.  Usually one or two; a handful of small components that only touch each other can
+        OBIA_HIP_TRY(hipMemsetAsync(tag, 0, sizeof(int) * (size_t)n_small, ctx->stream));
+        hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle);
+        // optimistic start (every small component labelled at its first pixel), then rounds on a work list until no settle
+        // time moves (cc_small_bfs_kernel); one round settles everything unless small components that find no labelled
+        // neighbour touch each other.
+        // (settle times only move forward, and a component's settle time is one of its own pixels or "never": at most
+        // small_px + 1 rounds move something.  Usually one to three; a handful of small components that only touch each other can
         // need more rounds than there are components -- found by tests/test_gpu_tiling_random.py -- so the bound is the pixel
         // count, not the component count.  Never cut short: an unconverged round would write label 0)
         bool converged = false;
-        for (long long round = 0; round <= (long long)small_px + 1; ++round) {
+        int n_items = n_small;
+        const int *work_in = nullptr;
+        for (long long round = 0; round <= (long long)small_px + 2; ++round) {
             OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
-                               small_list, small_qoff, n_small, start_label, settle_a, settle_b, queue, labels_out, target,
-                               counters + 5);
-            int changed = 0;
-            OBIA_TRY(read_back(ctx, &changed, counters + 5, sizeof(int)));
-            std::swap(settle_a, settle_b);
-            if (!changed) { converged = true; break; }
+            hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
+                               small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
+                               counters + 5, tag, (int)(round & 0x3fffffff));
+            int n_next = 0;
+            OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
+            if (n_next == 0) { converged = true; break; }
+            work_in = work_a;
+            std::swap(work_a, work_b);
+            n_items = n_next;
         }
         if (!converged) { set_error("connectivity enforcement: settle rounds did not converge (%d small components)", n_small); return OBIA_E_INVALID; }
     }
