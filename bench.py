@@ -41,8 +41,24 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy reaches
 
 
-def synth_raster(H, W, C, seed, device, row0=0):
-    """BASELINE.md 3 generator, on the device: band_c = 400 sin(x/(11+3c)) cos(y/(13+2c)) + 1000 + 50c + N(0,20^2)."""
+def synth_raster(H, W, C, seed, device, row0=0, host_rng=False):
+    """BASELINE.md 3 / SURVEY 8d generator: band_c = 400 sin(x/(11+3c)) cos(y/(13+2c)) + 1000 + 50c + N(0,20^2), float32.
+    The noise is drawn on the DEVICE by default (torch's Philox stream): SURVEY 8d words it as NumPy RandomState(seed) on the
+    host, which takes ~1 minute for the 2.1e9 normals of the headline raster -- same formula, same distribution, another stream
+    (DESIGN.md 4).  host_rng=True (--host-rng) draws with NumPy RandomState(seed), row block by row block, band by band, and
+    uploads once, outside every timed region."""
+    if host_rng:
+        rs = np.random.RandomState(seed)
+        out = torch.empty((H, W, C), device=device, dtype=torch.float32)
+        xx = np.arange(W, dtype=np.float32)[None, :]
+        for y0 in range(0, H, 2048):
+            h = min(2048, H - y0)
+            yy = np.arange(row0 + y0, row0 + y0 + h, dtype=np.float32)[:, None]
+            blk = np.empty((h, W, C), np.float32)
+            for c in range(C):
+                blk[:, :, c] = 400.0 * np.sin(xx / (11 + 3 * c)) * np.cos(yy / (13 + 2 * c)) + 1000 + 50 * c + rs.normal(0, 20, (h, W))
+            out[y0:y0 + h] = torch.from_numpy(blk).to(device)
+        return out
     g = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty((H, W, C), device=device, dtype=torch.float32)
     xx = torch.arange(W, device=device, dtype=torch.float32)[None, :]
@@ -111,7 +127,9 @@ def cpu_baseline(C, tile, buffer_, crown_radius, pixel, compactness):
     dt = time.time() - t0
     out = {"value": H * W / dt / 1e6, "unit": "Mpixel/s", "cores": 1, "kind": "port",
            "sample": f"one {tile}x{tile}x{C} tile of the workload (all-ones mask, n_segments={n}): normalise + "
-                     f"spatial pre-pass + 10 SLIC sweeps + connectivity + zonal stats, {dt:.1f} s on 1 thread"}
+                     f"spatial pre-pass + 10 SLIC sweeps + connectivity + zonal stats, {dt:.1f} s on 1 thread; the port seeds with the "
+                     "build's masked-grid rule (DESIGN.md 5) -- scikit-image's own _get_mask_centroids (kmeans2 + a K x K pdist at "
+                     f"K = {n}) would add minutes and gigabytes on top"}
     # the fair "all host cores" figure: the same tile in T independent processes (no GPU in the children)
     try:
         import subprocess
@@ -147,7 +165,8 @@ def main():
     ap.add_argument("--bands", type=int, default=8)
     ap.add_argument("--compactness", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-side", action="store_true", help="skip the side legs (exit_on_fixed_point, compactness 0.25, quickshift)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side legs (exit_on_fixed_point, compactness 0.25, quickshift, configs[3] whole)")
+    ap.add_argument("--host-rng", action="store_true", help="draw the raster's noise with NumPy RandomState on the host (SURVEY 8d's wording; ~1 min)")
     ap.add_argument("--config", choices=("c3", "c4"), default="c3",
                     help="c3: BASELINE configs[2] per GPU (weak scaling); c4: BASELINE configs[3], 32768^2 x 8 split over the ranks (strong)")
     args = ap.parse_args()
@@ -202,7 +221,7 @@ def main():
         workload = (f"{world * H}x{W}x{C} raster sharded over {world} GPUs ({H}-row slab per GPU = the N = 1 workload), "
                     f"tile={args.tile}, overlap={args.buffer}, seam exchange over RCCL send/recv")
     if world == 1:
-        img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)
+        img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0, host_rng=args.host_rng)
         mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
         ext_img = ext_mask = None
     else:
@@ -210,7 +229,7 @@ def main():
         # copies nothing per call
         top, bot = ShardedTiler.halo_rows(rank, world, args.buffer)
         ext_img = torch.empty((top + H + bot, W, C), dtype=torch.float32, device=dev)
-        ext_img[top:top + H] = synth_raster(H, W, C, seed=rank, device=dev, row0=row0)   # per-GPU slab seed = slab index
+        ext_img[top:top + H] = synth_raster(H, W, C, seed=rank, device=dev, row0=row0, host_rng=args.host_rng)   # per-GPU slab seed = slab index
         ext_mask = torch.ones((top + H + bot, W), dtype=torch.uint8, device=dev)
         img, mask = ext_img[top:top + H], ext_mask[top:top + H]
     ctx = _lib.Context(gpu)
@@ -341,8 +360,44 @@ def main():
         return {"workload": f"{S}x{S}x3 quickshift(kernel_size=5, max_dist=10) (BASELINE configs[4])", "value": round(S * S / d / 1e6, 2),
                 "unit": "Mpixel/s", "ms_per_call": round(d * 1e3, 2), "segments": int(ql.max().item()) + 1, "dtype": "f64"}
 
+    def c4_leg():
+        """BASELINE configs[3] WHOLE on this one GPU (32768 x 32768 x 8, tile 2048, overlap 64: 34 GB of raster), the same pipeline
+        as the headline.  The 8-GPU form of this configuration is `--config c4 --gpus 8` (strong scaling); this leg is what one
+        GPU does with the whole of it, so that the driver's default line carries a measured figure for the configuration."""
+        if world != 1 or args.no_side or args.config != "c3" or args.size != 16384:
+            return None
+        S = 32768
+        big = synth_raster(S, S, C, seed=0, device=dev)
+        bmask = torch.ones((S, S), dtype=torch.uint8, device=dev)
+        ctx4 = _lib.Context(gpu)
+        ctx4.set_profiling(2)
+        kw4 = dict(kw, ctx=ctx4)
+        lab4, n4 = create_tiled_segments(big, input_mask=bmask, **kw4)      # warm-up (sizes the workspace)
+        zonal_stats(big, lab4, n_labels=n4, ctx=ctx4)
+        torch.cuda.synchronize()
+        reps = max(1, min(args.steps, 3))
+        a_ms = a_px = a_spx = sw = 0.0
+        t1 = time.time()
+        for _ in range(reps):
+            lab4, n4 = create_tiled_segments(big, input_mask=bmask, **kw4)
+            tt = ctx4.timing()
+            a_ms += tt["assign_ms"]; a_px += tt["assign_px"]; a_spx += tt["assign_store_px"]; sw += tt["sweeps"]
+            zonal_stats(big, lab4, n_labels=n4, ctx=ctx4)
+        torch.cuda.synchronize()
+        d = (time.time() - t1) / reps
+        ach = (a_px * 4 * C + a_spx * 4) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+        out4 = {"workload": f"{S}x{S}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[3]), "
+                            "whole raster on one GPU", "value": round(float(S) * S / d / 1e6, 2), "unit": "Mpixel/s",
+                "ms_per_step": round(d * 1e3, 3), "steps": reps, "segments": int(n4),
+                "sweep_avg_launch_ms": round(a_ms / max(1.0, sw), 4), "sweep_roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
+        del big, bmask, lab4
+        ctx4.close()
+        torch.cuda.empty_cache()
+        return out4
+
     c025_leg = compactness_leg(0.25) if abs(args.compactness - 0.25) > 1e-9 else None
     qs_leg = quickshift_leg()
+    c4_whole = c4_leg()
     ms_per_step = dt / args.steps * 1e3
     total_px = float(H) * W * world
     value = total_px / (dt / args.steps) / 1e6
@@ -361,7 +416,7 @@ def main():
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" + (" (NumPy RandomState on the host)" if args.host_rng else " (SURVEY 8d formula, noise drawn on the device)"),
             "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,
                        "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
                        "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu"},
@@ -387,6 +442,7 @@ def main():
         out["with_exit_on_fixed_point"] = fp_leg
         out["compactness_0.25"] = c025_leg
         out["quickshift"] = qs_leg
+        out["c4_whole_on_one_gpu"] = c4_whole
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -644,6 +644,10 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     std::vector<int> nvalid;
     if (nvalid_in) nvalid = *nvalid_in;
     else OBIA_TRY(slic_count_valid(ctx, b, nvalid));
+    // caller-supplied seeds on a mask without a valid pixel: the reference raises before seeding (mask.sum() == 0).  Refused
+    // here, BEFORE anything is sized or uploaded: the seed arrays below would hold one dummy record while the upload wrote
+    // ext->n of them
+    if (ext && nvalid[0] <= 0) { set_error("the mask has no valid pixel"); return OBIA_E_EMPTY; }
     std::vector<SeedGrid> grids(np);
     std::vector<double> stepmax(np);
     int cent_off = 0;

@@ -232,6 +232,15 @@ __device__ __forceinline__ void global_accumulate(unsigned long long *__restrict
     atomicAdd(&a[CP + 2], (unsigned long long)x);
 }
 
+// store_labels: 0 = this sweep does not store its labels, 1 = it does but earlier sweeps of the batch did not (the very last
+// sweep of a batch whose labels are only stored at the end), 2 = every sweep of the batch stores.  A valid pixel that no window
+// reaches ("orphan") keeps the label of the sweep before: unless every sweep stored, that label is not in memory -- the pixel
+// would come out with the fill value where the reference keeps the label of sweep N-1 -- so the flag is raised and the host
+// repeats the batch with every sweep storing.  (Sweep 1 has no sweep before it: the fill value IS what the reference keeps.)
+__device__ __forceinline__ bool orphan_needs_repeat(int store_labels, int sweep_id) {
+    return store_labels == 0 || (store_labels == 1 && sweep_id > 1);
+}
+
 // Fallback for a tile whose candidate set does not fit the LDS slots: every lane scans the bins around
 // each of its pixels directly in global memory.  Same arithmetic, no staging.
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool SLICZERO>
@@ -239,7 +248,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                           const uint8_t *__restrict__ mask, const float *__restrict__ cent,
                           const int *__restrict__ head, int32_t *__restrict__ labels,
                           unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color, int start_label,
-                          float fs, int store_labels, int *__restrict__ orphan_flag) {
+                          float fs, int store_labels, int *__restrict__ orphan_flag, int sweep_id) {
     constexpr int RS = CENT_REC + CP;
     const float w = P.spatial_w;
     for (int i = threadIdx.x; i < SWEEP_TW * SWEEP_TH; i += NT) {
@@ -275,7 +284,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                 }
         int k = bk;
         if (k < 0) {   // `nearest` keeps the previous sweep's value
-            if (!store_labels) *orphan_flag = 1;   // ... which was not stored: the host repeats the batch with every sweep storing
+            if (orphan_needs_repeat(store_labels, sweep_id)) *orphan_flag = 1;   // ... which was not stored: the host repeats the batch with every sweep storing
             const int prev = labels[pix];
             if (prev >= start_label) k = prev - start_label + P.cent_off;
         } else {
@@ -527,7 +536,7 @@ __device__ __forceinline__ void slic_assign_body(
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
         slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
-                                                      accum_color, start_label, fs, store_labels, orphan_flag);
+                                                      accum_color, start_label, fs, store_labels, orphan_flag, sweep_id);
         return;
     }
     auto do_sort = [&]() {
@@ -789,7 +798,7 @@ __device__ __forceinline__ void slic_assign_body(
             }
         }
         if (__ballot(orphan)) {   // wave-uniform, rare
-            if (!store_labels && lane_i == 0) *orphan_flag = 1;   // the labels this pixel would keep were not stored: repeat the batch
+            if (orphan_needs_repeat(store_labels, sweep_id) && lane_i == 0) *orphan_flag = 1;   // the labels this pixel would keep were not stored: repeat the batch
 #pragma unroll
             for (int j = 0; j < PPT; ++j)
                 if (valid[j] && ((unsigned)(bk[j] >> 32) >= INF_BITS)) {
@@ -1031,7 +1040,7 @@ __global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__
 
 // A group of consecutive problems of the batch whose prep / sweep chain runs on its own stream (slic_run_sweeps): the
 // centroids [k0, k1), bins [cell0, cell1) and tiles [tile0, tile1) of the batch's tables.
-struct SweepGroup { int k0, k1, cell0, cell1, tile0, tile1; hipStream_t stream; };
+struct SweepGroup { int k0, k1, cell0, cell1, tile0, tile1; long long pix0, pix1; hipStream_t stream; };
 
 struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; null when the option is off)
     int *bin_stamp = nullptr, *tile_lp = nullptr, *cache_k = nullptr;
@@ -1178,6 +1187,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
             sg.k0 = P0.cent_off;   sg.k1 = last ? b.total_cent : b.probs[cut[g + 1]].cent_off;
             sg.cell0 = P0.cell_off; sg.cell1 = last ? b.total_cells : b.probs[cut[g + 1]].cell_off;
             sg.tile0 = P0.tile_off; sg.tile1 = last ? (int)b.total_tiles_all : b.probs[cut[g + 1]].tile_off;
+            sg.pix0 = P0.pix_off;   sg.pix1 = last ? b.total_pix : b.probs[cut[g + 1]].pix_off;
             sg.stream = g == 0 ? ctx->stream : ctx->side[g - 1];
             groups.push_back(sg);
         }
@@ -1202,6 +1212,19 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         for (int pass = 0; pass < passes; ++pass) {
             const int ignore_color = (b.masked && pass == 0) ? 1 : 0;
             const bool last_pass = (pass == passes - 1);
+            if (pass > 0 && store_all && sg.pix1 > sg.pix0) {
+                // the main pass is a second call of _slic_cython (slic_superpixels.py:310-318): `nearest` starts from the fill
+                // value again, a pixel no window reaches in its first sweep does not inherit a pre-pass label.  (Only when the
+                // pre-pass stored labels at all: otherwise the fill of the batch's start is still in place.)
+                const long long n = sg.pix1 - sg.pix0;
+                int blocks = cdiv(n, 256 * 8);
+                if (blocks > 65535) blocks = 65535;
+                hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, sg.stream, b.d_labels + sg.pix0, n, b.start_label - 1);
+                // (exit_on_fixed_point: no tile may replay "labels already in place" across the refill -- every tile of the group
+                // is evaluated by the first sweep of the main pass)
+                if (fp.tile_lp && sg.tile1 > sg.tile0)
+                    OBIA_HIP_TRY(hipMemsetAsync(fp.tile_lp + sg.tile0, 0, sizeof(int) * (size_t)(sg.tile1 - sg.tile0), sg.stream));
+            }
             for (int it = 0; it < b.max_iter; ++it) {
                 int *head_cur = b.d_head + (size_t)(sweep_no & 1) * b.total_cells;
                 int *head_nxt = b.d_head + (size_t)((sweep_no + 1) & 1) * b.total_cells;
@@ -1241,11 +1264,11 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 const bool very_last = last_pass && it == b.max_iter - 1;
                 const int accumulate = very_last ? 0 : 1;
                 const int accum_color = (!ignore_color || it == b.max_iter - 1) ? 1 : 0;
-                const int store_labels = (store_all || very_last) ? 1 : 0;
+                const int store_labels = store_all ? 2 : (very_last ? 1 : 0);   // (see orphan_needs_repeat)
                 // the last pre-pass sweep is the only one of its pass that folds colours (they seed the main pass): the
                 // caches written by the earlier pre-pass sweeps hold no colour sums, so it evaluates every tile
                 const int use_cache = (ignore_color && it == b.max_iter - 1) ? 0 : 1;
-                {
+                if (sg.tile1 > sg.tile0) {   // (an empty group launches nothing: no span either -- its pooled events would keep an older recording)
                     KernelSpan span(ctx, ignore_color ? T_PREPASS : T_ASSIGN);   // events bound to the dispatch
                     unsigned long long *pxc = ctx->profiling ? d_px + (ignore_color ? 256 : 0) : nullptr;
                     if (gi == 0 && ctx->profiling && !ignore_color && store_labels) ctx->timing.assign_store_px += (double)b.total_pix;

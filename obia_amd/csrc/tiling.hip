@@ -14,6 +14,8 @@
 //           segments within the polygon are dropped and re-segmented  tiling.py:220-231
 //           segments overlapping it are kept and masked out, together with the corner squares
 //                                                                    tiling.py:213-260
+//           ... but only when at least one existing segment is within / overlaps the polygon (tiling.py:212); otherwise
+//           the mask is left as read and the corner squares ARE segmented (tiling.py:261-262): tile_any[]
 //           n_segments = round(mask.sum() * pixel_area / (pi * crown_radius^2))   tiling.py:126-135
 //   ids 1..N in the order black (survivors), then white              tiling.py:289-290
 // All tiles of a pass (or of one white tile-row) are ONE batch for the SLIC engine and for the
@@ -45,9 +47,12 @@ __device__ __forceinline__ bool in_corner(const TileWin &t, int y, int x) {
 }
 
 // white tiles, step 1: pixels of every existing segment that lie inside the tile polygon
+// tile_any[tile] = 1 when some existing segment has a pixel inside the polygon: `not intersecting_black_segments.empty or not
+// intersecting_white_segments.empty` (tiling.py:205-212)
 __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ G,
-                                                                int Wr, unsigned *__restrict__ inside) {
+                                                                int Wr, unsigned *__restrict__ inside, int *__restrict__ tile_any) {
     const TileWin t = wins[blockIdx.y];
+    bool seen = false;
     const int wround = ((t.w + 255) / 256) * 256;   // whole waves stay in the loop for the wave-level histogram
     for (int y = blockIdx.x; y < t.h; y += gridDim.x)
         for (int x0 = 0; x0 < wround; x0 += 4 * 256) {   // four loads in flight
@@ -57,11 +62,13 @@ __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *_
                 const int x = x0 + 256 * u + threadIdx.x;
                 g[u] = 0;
                 if (x < t.w && !in_corner(t, y, x)) g[u] = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+                seen |= g[u] > 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (x0 + 256 * u < wround) wave_hist_add(inside, g[u], g[u] > 0);   // wave-uniform condition
         }
+    if (__ballot(seen) && (threadIdx.x & 63) == 0) tile_any[blockIdx.y] = 1;   // (every writer stores the same value)
 }
 
 // step 2: dense tile mask.  black: the input mask.  white: input mask minus kept (overlapping) segments
@@ -70,8 +77,12 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restrict__ wins, const uint8_t *__restrict__ inmask,
                                                         int32_t *__restrict__ G, int Wr, int white,
                                                         const unsigned *__restrict__ inside, const unsigned *__restrict__ seg_size,
-                                                        uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask) {
+                                                        uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask,
+                                                        const int *__restrict__ tile_any) {
     const TileWin t = wins[blockIdx.y];
+    // a white tile whose polygon no existing segment intersects keeps the mask it read: neither kept segments (there are none
+    // inside the polygon) nor the corner squares are masked out (tiling.py:212, 261-262)
+    if (white && tile_any[blockIdx.y] == 0) white = 0;
     // one pixel of the tile: its mask byte given the input mask byte and the global label under it
     auto decide = [&](int y, int x, long long gp, uint8_t m, int g) -> uint8_t {
         if (!white) return m;
@@ -363,9 +374,12 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     if (!d_wins || !b.d_windows || !b.d_mask || !b.d_feat || !b.d_labels || !d_final) return OBIA_E_NOMEM;
     OBIA_TRY(upload_async(ctx, d_wins, wins.data(), sizeof(TileWin) * np));   // (pinned ring: no stream sync per small table)
     OBIA_TRY(upload_async(ctx, b.d_windows, b.windows.data(), sizeof(SrcWindow) * np));
+    int *d_tile_any = A.get<int>(np);
+    if (!d_tile_any) return OBIA_E_NOMEM;
     if (white) {
         OBIA_HIP_TRY(hipMemsetAsync(S.inside, 0, sizeof(unsigned) * (size_t)S.next_id, ctx->stream));
-        hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside);
+        OBIA_HIP_TRY(hipMemsetAsync(d_tile_any, 0, sizeof(int) * (size_t)np, ctx->stream));
+        hipLaunchKernelGGL(tile_count_inside_kernel, dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.G, S.W, S.inside, d_tile_any);
     }
     {
         bool vec4 = (S.W % 4 == 0) && (reinterpret_cast<uintptr_t>(S.inmask) % 4 == 0) && (reinterpret_cast<uintptr_t>(S.G) % 16 == 0) &&
@@ -373,10 +387,10 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         for (auto &t : wins) vec4 = vec4 && (t.x0 % 4 == 0) && (t.w % 4 == 0) && (t.pix_off % 4 == 0);
         if (vec4)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<true>), dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
-                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask, d_tile_any);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<false>), dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
-                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask);
+                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask, d_tile_any);
     }
     // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
     std::vector<int> skip;

@@ -98,10 +98,101 @@ class HipTilerEngine:
             self.h = None
 
 
-def _p2p(ops):
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+class TorchComm:
+    """Seam traffic over a torch.distributed process group: RCCL ("nccl", one rank per GPU, device tensors on the wire)
+    or gloo (CPU tests; device tensors are staged through the host)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.host_wire = dist.get_backend(group) == "gloo"
+
+    def wire(self, t):
+        """a contiguous tensor on the device the backend sends from"""
+        t = t.contiguous()
+        return t.cpu() if (self.host_wire and t.is_cuda) else t
+
+    def wire_device(self, dev):
+        return "cpu" if self.host_wire else dev
+
+    def exchange(self, sends, recvs):
+        """sends: [(tensor, peer)], recvs: [(buffer, peer)] -- one batch of point-to-point operations, waited for"""
+        ops = [dist.P2POp(dist.isend, t, peer, self.group) for t, peer in sends]
+        ops += [dist.P2POp(dist.irecv, b, peer, self.group) for b, peer in recvs]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def all_gather_ints(self, values, dev):
+        """every rank's list of host integers (the only collective of the driver: two integers per rank, once per call)"""
+        mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self.wire_device(dev))
+        allv = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allv, mine, group=self.group)
+        return [[int(x) for x in v.tolist()] for v in allv]
+
+
+class ThreadComm:
+    """The same interface for ranks that are THREADS of one process sharing one GPU (or the CPU): mailboxes instead of a
+    process group.  It exists so that the exact slab partition of a many-GPU run (BASELINE configs[3]: 8 slabs) can be
+    rehearsed on a one-GPU box, where only a few processes may hold the card; the protocol code above it is the same.
+    ``ThreadComm.make(world)`` returns one endpoint per rank."""
+
+    class _Hub:
+        def __init__(self, world):
+            import queue
+            import threading
+            self.world = world
+            self.box = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+            self.aborted = False
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+        self.host_wire = False
+
+    @staticmethod
+    def make(world):
+        hub = ThreadComm._Hub(world)
+        return [ThreadComm(hub, r) for r in range(world)]
+
+    def wire(self, t):
+        return t.contiguous()
+
+    def wire_device(self, dev):
+        return dev
+
+    def abort(self):
+        """a rank that failed tells the others, so that nobody waits for its mail"""
+        self.hub.aborted = True
+        self.hub.barrier.abort()
+
+    def _take(self, q):
+        import queue
+        for _ in range(1200):
+            if self.hub.aborted:
+                raise RuntimeError("another rank of the thread group failed")
+            try:
+                return q.get(timeout=0.5)
+            except queue.Empty:
+                continue
+        raise RuntimeError("timed out waiting for a neighbour's message")
+
+    def exchange(self, sends, recvs):
+        for t, peer in sends:
+            m = t.clone()                                              # the copy is what the peer reads
+            if m.is_cuda:
+                torch.cuda.current_stream(m.device).synchronize()
+            self.hub.box[(self.rank, peer)].put(m)
+        for b, peer in recvs:
+            b.copy_(self._take(self.hub.box[(peer, self.rank)]).reshape(b.shape))
+
+    def all_gather_ints(self, values, dev):
+        self.hub.slots[self.rank] = [int(v) for v in values]
+        self.hub.barrier.wait(timeout=600)
+        out = [list(v) for v in self.hub.slots]
+        self.hub.barrier.wait(timeout=600)
+        return out
 
 
 class ShardedTiler:
@@ -120,10 +211,10 @@ class ShardedTiler:
         return (hb if rank > 0 else 0, hb if rank < world - 1 else 0)
 
     def __init__(self, slab, mask_slab, global_rows, tile_rows_per_rank, tile_size, buffer, crown_radius=5,
-                 pixel_size=(1.0, 1.0), engine_factory=None, group=None, ctx=None, ext_image=None, ext_mask=None,
+                 pixel_size=(1.0, 1.0), engine_factory=None, group=None, ctx=None, ext_image=None, ext_mask=None, comm=None,
                  **slic_kwargs):
-        self.group = group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.comm = comm if comm is not None else TorchComm(group)
+        self.rank, self.world = self.comm.rank, self.comm.world
         if self.world > 127:
             raise ValueError("at most 127 ranks (segment codes keep the owner in 7 bits)")
         self.T, self.B, self.hb = int(tile_size), int(buffer), int(buffer) + 1
@@ -140,7 +231,6 @@ class ShardedTiler:
         if self.world > 1 and Hs < self.hb:
             raise ValueError("slab shorter than the halo")
         self.dev = slab.device
-        self.cpu_comm = dist.get_backend(group) == "gloo" and slab.is_cuda
         self.top = self.hb if self.rank > 0 else 0
         self.bot = self.hb if self.rank < self.world - 1 else 0
         # ---- halo exchange of image and mask rows (once) ------------------------------------------------------
@@ -187,21 +277,20 @@ class ShardedTiler:
 
     # ---- communication helpers ---------------------------------------------------------------------------------
     def _to_wire(self, t):
-        t = t.contiguous()
-        return t.cpu() if self.cpu_comm else t
+        return self.comm.wire(t)
 
     def _exchange_rows(self, ext, send_top, send_bot):
         """fill the halo rows of `ext` from the neighbours; they get my first / last hb rows"""
-        ops, bufs = [], {}
+        sends, recvs, bufs = [], [], {}
         if self.rank > 0:
             bufs["up"] = torch.empty_like(self._to_wire(send_top))
-            ops.append(dist.P2POp(dist.isend, self._to_wire(send_top), self.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, bufs["up"], self.rank - 1, self.group))
+            sends.append((self._to_wire(send_top), self.rank - 1))
+            recvs.append((bufs["up"], self.rank - 1))
         if self.rank < self.world - 1:
             bufs["down"] = torch.empty_like(self._to_wire(send_bot))
-            ops.append(dist.P2POp(dist.isend, self._to_wire(send_bot), self.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, bufs["down"], self.rank + 1, self.group))
-        _p2p(ops)
+            sends.append((self._to_wire(send_bot), self.rank + 1))
+            recvs.append((bufs["down"], self.rank + 1))
+        self.comm.exchange(sends, recvs)
         if "up" in bufs:
             ext[:self.top] = bufs["up"].to(ext.device)
         if "down" in bufs:
@@ -231,38 +320,54 @@ class ShardedTiler:
     def _ids_of(self, codes, owners):
         """int32 wire codes -> local ids; foreign codes not seen before get local ids (one contiguous range per owner,
         reserved in the engine).  ``owners``: the ranks whose segments can occur (the sender and, through it, nobody
-        else: a slab is taller than a window's reach)."""
+        else: a slab is taller than a window's reach).
+        The map of an owner's ids is sized to the ids that DO occur, not to the 2^24 a code can carry (round 2 kept a dense
+        64-MB table per neighbour and swept it eight times per import): it starts at twice this rank's own id count -- slabs
+        of one raster hold similar numbers of segments -- and doubles past the largest id on a seam; that largest id rides
+        in the import's one read-back, and an import whose seam outgrew the map is simply evaluated again on the grown map."""
         codes = codes.to(torch.int64)
         their = codes & ID_MASK
         owner = (codes >> CODE_SHIFT) - 1
         ids = torch.where(owner == self.rank, their, torch.zeros_like(their))
+        gdev = self.G.device
         for nb in owners:
             sel = (owner == nb) & (codes > 0)
+            t = torch.where(sel, their, torch.zeros_like(their))            # index 0 is a dummy entry
             fm = self.fmap.get(nb)
             if fm is None:
-                fm = self.fmap[nb] = torch.zeros((1 << CODE_SHIFT,), dtype=torch.int32, device=self.G.device)
-            t = torch.where(sel, their, torch.zeros_like(their))            # index 0 is a dummy entry
-            known = fm[t] != 0
-            flag = torch.zeros_like(fm)
-            flag.index_put_((torch.where(sel & ~known, t, torch.zeros_like(t)).reshape(-1),),
-                            torch.ones((), dtype=torch.int32, device=fm.device))
-            flag[0] = 0
-            rank_in_new = torch.cumsum(flag, 0, dtype=torch.int32)
-            n_new = int(rank_in_new[-1].item())                             # the one read-back of an import
+                cap0 = 1 << max(12, (2 * int(self.engine.next_id())).bit_length())
+                fm = self.fmap[nb] = torch.zeros((min(cap0, 1 << CODE_SHIFT),), dtype=torch.int32, device=gdev)
+            while True:
+                cap = fm.numel()
+                inb = t < cap
+                tc = torch.where(inb, t, torch.zeros_like(t))
+                known = fm[tc] != 0
+                flag = torch.zeros_like(fm)
+                flag.index_put_((torch.where(sel & inb & ~known, tc, torch.zeros_like(tc)).reshape(-1),),
+                                torch.ones((), dtype=torch.int32, device=gdev))
+                flag[0] = 0
+                rank_in_new = torch.cumsum(flag, 0, dtype=torch.int32)
+                n_new, t_max = torch.stack((rank_in_new[-1].to(torch.int64), t.max())).tolist()   # the one read-back of an import
+                if t_max < cap:
+                    break
+                grown = torch.zeros((min(1 << CODE_SHIFT, 1 << (2 * int(t_max) + 2).bit_length()),), dtype=torch.int32, device=gdev)
+                grown[:cap] = fm
+                fm = self.fmap[nb] = grown
+                self.stats["map_growths"] = self.stats.get("map_growths", 0) + 1
             if n_new:
                 first = self._check_ids()
                 # reserve the range in the engine; sizes follow in _refresh_foreign_sizes
-                self.engine.set_segments(first, torch.full((n_new,), HUGE, dtype=torch.int64, device=self.G.device))
+                self.engine.set_segments(first, torch.full((n_new,), HUGE, dtype=torch.int64, device=gdev))
                 fm = self.fmap[nb] = torch.where(flag != 0, rank_in_new + (first - 1), fm)
                 self._check_ids()
                 # codes of the new ids (rank order == ascending ids of the owner); entries that are not new land on the dummy id 0
-                their_all = torch.arange(fm.numel(), dtype=torch.int32, device=fm.device)
+                their_all = torch.arange(fm.numel(), dtype=torch.int32, device=gdev)
                 self.code_of.index_put_((torch.where(flag != 0, fm, torch.zeros_like(fm)).to(torch.int64),),
                                         torch.where(flag != 0, their_all + ((nb + 1) << CODE_SHIFT), torch.zeros_like(their_all)))
                 self.code_of[0] = 0
                 self.f_batches.append((nb, first, n_new))
                 self.stats["foreign_ids"] += n_new
-            ids = torch.where(sel, fm[t].to(torch.int64), ids)
+            ids = torch.where(sel, fm[tc].to(torch.int64), ids)
         self.stats["imports"] += 1
         return ids
 
@@ -306,20 +411,20 @@ class ShardedTiler:
     def _white_class(self, cls):
         au, pu, ad, pd = self._seam_roles(cls)
         hb, top, Hs = self.hb, self.top, self.Hs
-        wdev = "cpu" if self.cpu_comm else self.G.device
+        wdev = self.comm.wire_device(self.G.device)
         # 1. passive sides send their boundary label rows (int32 codes); active sides import them into their halo
-        ops, rbuf = [], {}
+        sends, recvs, rbuf = [], [], {}
         if pu:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._codes_of(self.G[top:top + hb])), self.rank - 1, self.group))
+            sends.append((self._to_wire(self._codes_of(self.G[top:top + hb])), self.rank - 1))
         if pd:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._codes_of(self.G[top + Hs - hb:top + Hs])), self.rank + 1, self.group))
+            sends.append((self._to_wire(self._codes_of(self.G[top + Hs - hb:top + Hs])), self.rank + 1))
         if au:
             rbuf["up"] = torch.empty((hb, self.W), dtype=torch.int32, device=wdev)
-            ops.append(dist.P2POp(dist.irecv, rbuf["up"], self.rank - 1, self.group))
+            recvs.append((rbuf["up"], self.rank - 1))
         if ad:
             rbuf["down"] = torch.empty((hb, self.W), dtype=torch.int32, device=wdev)
-            ops.append(dist.P2POp(dist.irecv, rbuf["down"], self.rank + 1, self.group))
-        _p2p(ops)
+            recvs.append((rbuf["down"], self.rank + 1))
+        self.comm.exchange(sends, recvs)
         if au:
             self.G[:top] = self._ids_of(rbuf["up"].to(self.G.device), (self.rank - 1,)).to(self.G.dtype)
         if ad:
@@ -333,18 +438,18 @@ class ShardedTiler:
         # 3. active sides send the halo rows back, followed by hb rows that list the neighbour's segments they dropped
         #    ([count, code, code, ...]: every imported segment has a pixel in the hb rows, so the list always fits);
         #    the owner overwrites its boundary rows and clears those segments
-        ops, rbuf = [], {}
+        sends, recvs, rbuf = [], [], {}
         if au:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[:top], self.rank - 1, "kills_sent_up")), self.rank - 1, self.group))
+            sends.append((self._to_wire(self._rows_with_kills(self.G[:top], self.rank - 1, "kills_sent_up")), self.rank - 1))
         if ad:
-            ops.append(dist.P2POp(dist.isend, self._to_wire(self._rows_with_kills(self.G[top + Hs:], self.rank + 1, "kills_sent_down")), self.rank + 1, self.group))
+            sends.append((self._to_wire(self._rows_with_kills(self.G[top + Hs:], self.rank + 1, "kills_sent_down")), self.rank + 1))
         if pu:
             rbuf["up"] = torch.empty((2 * hb, self.W), dtype=torch.int32, device=wdev)
-            ops.append(dist.P2POp(dist.irecv, rbuf["up"], self.rank - 1, self.group))
+            recvs.append((rbuf["up"], self.rank - 1))
         if pd:
             rbuf["down"] = torch.empty((2 * hb, self.W), dtype=torch.int32, device=wdev)
-            ops.append(dist.P2POp(dist.irecv, rbuf["down"], self.rank + 1, self.group))
-        _p2p(ops)
+            recvs.append((rbuf["down"], self.rank + 1))
+        self.comm.exchange(sends, recvs)
         if pu:
             buf = rbuf["up"].to(self.G.device)
             self.G[top:top + hb] = self._ids_of(buf[:hb], (self.rank - 1,)).to(self.G.dtype)
@@ -361,6 +466,9 @@ class ShardedTiler:
         out = torch.zeros((2 * nr, self.W), dtype=torch.int32, device=self.G.device)
         out[:nr] = self._codes_of(rows)
         fid = self._foreign_ids(owner_rank)
+        if fid.numel() > nr * self.W - 1:      # host integers: the list below holds one slot per dropped segment, after the count
+            raise RuntimeError(f"rank {self.rank}: {fid.numel()} segments imported from rank {owner_rank} cannot be listed in "
+                               f"{nr} x {self.W} seam entries")
         if fid.numel():
             alive = self.engine.get_alive(self._check_ids()).to(torch.bool)
             dead = ~alive[fid]
@@ -407,22 +515,20 @@ class ShardedTiler:
             own[fid] = False
         newid = torch.cumsum(own.to(torch.int64), 0) * own.to(torch.int64)        # 1-based rank among my alive segments
         n_alive = int(own.sum().item())
-        cdev = "cpu" if self.cpu_comm else self.G.device
-        mine = torch.tensor([n_alive, nid], dtype=torch.int64, device=cdev)
-        allv = [torch.zeros_like(mine) for _ in range(self.world)]
-        dist.all_gather(allv, mine, group=self.group)
-        counts = [int(v[0].item()) for v in allv]
-        nids = [int(v[1].item()) for v in allv]
+        allv = self.comm.all_gather_ints([n_alive, nid], self.G.device)
+        counts = [v[0] for v in allv]
+        nids = [v[1] for v in allv]
         offset = [sum(counts[:r]) for r in range(self.world)]
         # the neighbours' numbering of THEIR segments that live in my rows: exchange the newid tables (small)
+        cdev = self.comm.wire_device(self.G.device)
         tables = {self.rank: newid}
-        ops, rb = [], {}
+        sends, recvs, rb = [], [], {}
         for nb in (self.rank - 1, self.rank + 1):
             if 0 <= nb < self.world:
-                ops.append(dist.P2POp(dist.isend, self._to_wire(newid), nb, self.group))
+                sends.append((self._to_wire(newid), nb))
                 rb[nb] = torch.empty((nids[nb],), dtype=torch.int64, device=cdev)
-                ops.append(dist.P2POp(dist.irecv, rb[nb], nb, self.group))
-        _p2p(ops)
+                recvs.append((rb[nb], nb))
+        self.comm.exchange(sends, recvs)
         for nb, t in rb.items():
             tables[nb] = t.to(self.G.device)
         lut = torch.where(own, newid + offset[self.rank], torch.zeros_like(newid))
@@ -471,12 +577,12 @@ class ShardedTiler:
 
 
 def create_tiled_segments_sharded(slab, mask_slab=None, *, global_rows, tile_rows_per_rank, tile_size=200, buffer=30,
-                                  crown_radius=5, pixel_size=(1.0, 1.0), engine_factory=None, group=None, **slic_kwargs):
+                                  crown_radius=5, pixel_size=(1.0, 1.0), engine_factory=None, group=None, comm=None, **slic_kwargs):
     """Sharded ``create_tiled_segments``: every rank passes its slab (whole tile rows of the global raster, rank r
     holding tile rows [r*tile_rows_per_rank, ...)).  Returns (labels of the slab with global ids 1..N, N); the
     partition equals the single-GPU result with ``white_order="parity"``."""
     t = ShardedTiler(slab, mask_slab, global_rows, tile_rows_per_rank, tile_size, buffer, crown_radius, pixel_size,
-                     engine_factory, group, **slic_kwargs)
+                     engine_factory, group, comm=comm, **slic_kwargs)
     try:
         return t.run()
     finally:

@@ -35,6 +35,7 @@ class OracleTiler:
         self.sizes = {}
         self.alive = {}
         self.next_id = 1
+        self.untouched_white_tiles = []  # white tiles (tj, ti) that took the else branch of tiling.py:212 (tests)
         cl = self.B / 2.0
         self.clx = max(0, int(math.ceil(cl / self.pw - 0.5))) if self.B > 0 else 0
         self.cly = max(0, int(math.ceil(cl / self.ph - 0.5))) if self.B > 0 else 0
@@ -93,14 +94,20 @@ class OracleTiler:
                     corner[h - cy:, w - cx:] = True
                 sub = self.G[y0:y1, x0:x1]
                 tmask = self.inmask[y0:y1, x0:x1].copy()
-                inside = sub[~corner]
+                inside = sub[~corner]                          # tile_polygon = window minus the corner squares (:187-203)
                 ids, cnt = np.unique(inside[inside > 0], return_counts=True)
-                for g, c in zip(ids, cnt):
-                    if c == self.sizes[g]:                     # within(tile_polygon): dropped (:220-231)
-                        sub[sub == g] = 0
-                        self.alive[g] = False
-                tmask[sub > 0] = False                         # overlaps: kept and masked out (:213-255)
-                tmask[corner] = False                          # corner squares (:189-203, :248)
+                if len(ids):                                   # some segment is within / overlaps the polygon (:205-212)
+                    for g, c in zip(ids, cnt):
+                        if c == self.sizes[g]:                 # within(tile_polygon): dropped (:220-231)
+                            sub[sub == g] = 0
+                            self.alive[g] = False
+                    tmask[sub > 0] = False                     # overlaps: kept and masked out (:213-218, :233-244, :257-258)
+                    tmask[corner] = False                      # the corner squares join the mask in THIS branch only (:245-246)
+                else:
+                    self.untouched_white_tiles.append((tj, ti))
+                # else (:261-262): no segment intersects the polygon -- the mask is left as read, the corner squares
+                # ARE segmented (and a segment that lies wholly inside a corner square is written over in G: a label
+                # raster cannot hold the reference's two overlapping polygons)
                 self._run_tile(y0, x0, h, w, tmask)
 
     def finalize(self):

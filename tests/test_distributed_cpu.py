@@ -99,12 +99,12 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,H,W,R,mask_on", [(2, 200, 230, 2, False), (2, 240, 170, 2, True), (3, 300, 150, 1, False),
-                                                 (4, 400, 170, 2, "seam")])
+                                                 (4, 400, 170, 2, "seam"), (8, 800, 130, 2, "seam")])
 def test_sharded_equals_single_process_parity_order(tmp_path, oracle, world, H, W, R, mask_on):
     """world 4: two tile rows per rank, a mask that empties tiles on both sides of seams, segments dropped across seams in
     both directions (the kill lists travel up AND down) -- still exactly the single-process partition."""
     from oracle import tiler
-    kw = dict(tile_size=50 if (world == 2 and not mask_on) or world == 4 else 60 if mask_on else 100, buffer=8, crown_radius=3,
+    kw = dict(tile_size=50 if (world == 2 and not mask_on) or world >= 4 else 60 if mask_on else 100, buffer=8, crown_radius=3,
               pixel_size=(1.0, 1.0), compactness=10.0)
     T = kw["tile_size"]
     assert -(-H // T) <= world * R
@@ -124,6 +124,56 @@ def test_sharded_equals_single_process_parity_order(tmp_path, oracle, world, H, 
     assert stats[:, 2].sum() > 0                         # foreign segments were imported
     if world == 4:
         assert stats[:, 0].sum() > 0 and stats[:, 1].sum() > 0, f"kill lists must cross seams in both directions: {stats}"
+
+
+def _thread_rank(comm, img, mask, H, R, kw, out):
+    from obia_amd.distributed import ShardedTiler
+    T = kw["tile_size"]
+    r = comm.rank
+    lo, hi = r * R * T, min(H, (r + 1) * R * T)
+    ekw = dict(kw)
+    t = ShardedTiler(torch.from_numpy(img[lo:hi].copy()), None if mask is None else torch.from_numpy(mask[lo:hi].astype(np.uint8)),
+                     H, R, T, kw["buffer"], comm=comm, engine_factory=lambda im, m, Hg, row0, extra: OracleEngine(im, m, Hg, row0, ekw))
+    labels, n = t.run()
+    out[r] = (labels.numpy(), n, dict(t.stats))
+
+
+def test_eight_slabs_as_threads_of_one_process(oracle):
+    """BASELINE configs[3]'s partition -- EIGHT slabs of two tile rows each -- with the ranks as threads of one process
+    (obia_amd.distributed.ThreadComm: mailboxes instead of a process group; the protocol code is the same).  This is the form in
+    which the 8-slab case also runs on the one-GPU box (tests/test_gpu_distributed.py), where 8 processes may not share the card."""
+    import threading
+    from obia_amd.distributed import ThreadComm
+    from oracle import tiler
+    world, R, H, W = 8, 2, 800, 150
+    kw = dict(tile_size=50, buffer=8, crown_radius=3, pixel_size=(1.0, 1.0), compactness=10.0)
+    img = synth(H, W, 3, seed=2)
+    mask = np.ones((H, W), bool)
+    mask[60:160, 0:55] = False; mask[180:215, 100:150] = False; mask[290:300, :] = False; mask[480:530, 30:90] = False
+    comms = ThreadComm.make(world)
+    out, errs = {}, []
+
+    def run(c):
+        try:
+            _thread_rank(c, img, mask, H, R, kw, out)
+        except BaseException as e:      # a rank that dies must not leave the others waiting for its mail for ten minutes
+            errs.append((c.rank, repr(e)))
+            c.abort()
+            raise
+    th = [threading.Thread(target=run, args=(c,), daemon=True) for c in comms]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, errs
+    assert len(out) == world
+    lab = np.concatenate([out[r][0] for r in range(world)], 0)
+    ref, n_ref = tiler.create_tiled_segments(img, mask, white_order=1, **kw)
+    assert all(out[r][1] == n_ref for r in range(world))
+    assert np.array_equal(lab == 0, ref == 0) and adjusted_rand_index(lab, ref) == 1.0
+    ids = np.unique(lab[lab > 0])
+    assert ids[0] == 1 and ids[-1] == n_ref and len(ids) == n_ref
+    assert sum(out[r][2]["foreign_ids"] for r in range(world)) > 0
 
 
 def test_sharded_driver_rejects_small_tiles_and_unknown_kwargs():

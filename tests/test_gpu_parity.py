@@ -205,6 +205,50 @@ def test_seeded_slic_rejects_bad_seeds(amd):
         slic(img.cpu().numpy(), seeds=(np.array([[5.0, 5.0]]), [1.0, 8.0, 8.0]), _normalize_bands=True)   # host arrays: no seeds
 
 
+def test_seeded_slic_on_an_empty_mask_is_refused_before_any_upload(amd):
+    """caller-supplied seeds on a mask without a valid pixel used to upload n seeds into a one-record array
+    (device-side overflow) before OBIA_E_EMPTY was returned.  Refused up front now; the context stays usable."""
+    from obia_amd.segmentation import slic
+    img = dev(np.random.RandomState(0).rand(48, 56, 4).astype(np.float32))
+    seeds = (np.stack([np.linspace(2, 45, 300), np.linspace(2, 53, 300)], 1), [1.0, 6.0, 6.0])
+    for _ in range(3):
+        with pytest.raises(ValueError):
+            slic(img, mask=np.zeros((48, 56), bool), seeds=seeds, _normalize_bands=True)
+    ok = slic(img, mask=np.ones((48, 56), bool), seeds=seeds, _normalize_bands=True)      # same context, same seeds
+    assert int(ok.max().item()) >= 1
+
+
+def test_orphan_that_first_appears_in_the_very_last_sweep(amd, oracle):
+    """only the last sweep of a batch stores labels; a valid pixel that no window reaches ("orphan") keeps the
+    label of the sweep before, so the sweeps are repeated with every sweep storing.  The flag that triggers the repeat was
+    not raised by the LAST sweep itself: a pixel orphaned there for the first time came out with the fill value.
+    Case built with the oracle (tools: per-sweep coverage): a two-pixel island 2 * step rows above a ragged-edged region,
+    max_num_iter = 2 -- covered in both pre-pass sweeps and in the first colour sweep, out of every window in the second."""
+    from obia_amd.segmentation import slic
+    rs = np.random.RandomState(114)
+    H, W, C = int(rs.choice([80, 96, 110])), int(rs.choice([100, 120, 140])), int(rs.choice([1, 2, 4]))
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.stack([300 * np.sin(xx / (5 + 2 * c)) * np.cos(yy / (6 + c)) + 800 + 40 * c + rs.normal(0, 25, (H, W))
+                    for c in range(C)], -1).astype(np.float32)
+    n_seg = int(rs.choice([40, 60, 90])); top = int(rs.choice([40, 44, 48, 52])); comp = float(rs.choice([5.0, 20.0]))
+    mask = np.zeros((H, W), np.uint8); mask[top:, :] = 1
+    for x in range(W):
+        mask[top - int(rs.randint(0, 6)):top, x] = 1
+    assert (H, W, C, n_seg, top, comp) == (110, 140, 4, 60, 44, 5.0)
+    mask[11, 20:22] = 1                                   # the island
+    kw = dict(n_segments=n_seg, compactness=comp, convert2lab=False, start_label=1)
+    ref, ref_pre, _ = oracle.slic(oracle.normalize(img), return_all=True, max_iter=2, mask=mask, **kw)
+    one, one_pre, _ = oracle.slic(oracle.normalize(img), return_all=True, max_iter=1, mask=mask, **kw)
+    assert (ref_pre[11, 20:22] >= 1).all(), "the oracle keeps the label of the sweep before for the island"
+    got_pre = slic(dev(img), mask=mask.astype(bool), _normalize_bands=True, _stage="pre", max_num_iter=2, **kw).cpu().numpy()
+    assert np.array_equal(got_pre[11, 20:22], ref_pre[11, 20:22])
+    assert np.array_equal(got_pre, ref_pre)
+    got = slic(dev(img), mask=mask.astype(bool), _normalize_bands=True, max_num_iter=2, **kw).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # with the fixed-point cache and with SLIC-zero every sweep stores from the start: same answer
+    assert np.array_equal(slic(dev(img), mask=mask.astype(bool), _normalize_bands=True, max_num_iter=2, exit_on_fixed_point=True, **kw).cpu().numpy(), ref)
+
+
 def test_seeded_grid_equals_library_seeding(amd, oracle):
     """Feeding the plain grid through the seeds input must reproduce the library's own grid seeding bit for bit."""
     from obia_amd.segmentation import slic

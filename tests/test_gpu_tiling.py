@@ -81,6 +81,34 @@ def test_tiled_with_mask_and_empty_tiles(oracle):
     assert n2 == n and np.array_equal(lab2.cpu().numpy(), lab)
 
 
+def test_white_tile_without_neighbouring_segments_keeps_its_mask(oracle):
+    """tiling.py:212 / 261-262: the overlapping segments AND the two corner squares are masked out only when at least one existing
+    segment is within / overlaps the tile polygon; a white tile that meets none keeps the mask it read, so its corner squares are
+    segmented.  Islands of valid pixels that cover whole grown windows of white tiles (corners included), everything else masked:
+    the black tiles around them are empty."""
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    H, W, T, B = 330, 350, 100, 16
+    img = synth(H, W, 4, seed=9)
+    mask = np.zeros((H, W), bool)
+    mask[0:100, 100:200] = True           # white tile (0, 1) itself ...
+    mask[100:116, 84:100] = True          # ... and the parts of its grown window that hold its two corner squares (they lie in the
+    mask[100:116, 200:216] = True         #     white tiles (1, 0) and (1, 2)); the black tiles around it have no valid pixel
+    mask[184:316, 184:316] = True         # a black tile with neighbours, for contrast
+    kw = dict(tile_size=T, buffer=B, crown_radius=5, pixel_size=(1.0, 1.0), compactness=10.0)
+    t = tiler.OracleTiler(img, mask, H, 0, **kw)
+    nty = -(-H // T)
+    t.run(False, 0, nty)
+    t.run(True, 0, 1)                     # the first white tile row only: tile (0, 1)
+    assert (0, 1) in t.untouched_white_tiles, "the case must reach the else branch (tiling.py:261-262)"
+    assert (t.G[108:116, 84:92] > 0).all() and (t.G[108:116, 208:216] > 0).all(), "its corner squares are segmented by tile (0, 1)"
+    t.run(True, 1, nty)
+    ref, n_ref = t.finalize()
+    lab, n = create_tiled_segments(img, input_mask=mask, **kw)
+    assert n == n_ref and np.array_equal(lab, ref), f"{(lab != ref).sum()} px differ, n {n} vs {n_ref}"
+    assert (lab[~mask] == 0).all()
+
+
 def test_tiled_errors():
     from obia_amd.tiling import create_tiled_segments
     img = synth(64, 64, 4)
