@@ -47,7 +47,10 @@ __device__ unsigned long long g_tl[65536 * 4 * 24];
 #define STAMP_DECL unsigned long long st_t = clock64(), st_t0 = st_t, st_r0 = __builtin_amdgcn_s_memrealtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_cnt[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP_COUNT(i, v) st_cnt[i] += (v);
 #define STAMP(i) { const unsigned long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; }
-#define STAMP_FLUSH if (accumulate && (threadIdx.x & 63) == 0 && gtile < 65536) { unsigned long long *st_o = g_tl + ((size_t)gtile * 4 + (threadIdx.x >> 6)) * 24; for (int st_i = 0; st_i < 12; ++st_i) st_o[st_i] = st_acc[st_i]; st_o[12] = st_t0; st_o[13] = clock64(); st_o[14] = st_r0; st_o[15] = __builtin_amdgcn_s_memrealtime(); for (int st_i = 0; st_i < 6; ++st_i) st_o[16 + st_i] = st_cnt[st_i]; }
+#ifndef OBIA_STAMP_KIND
+#define OBIA_STAMP_KIND 0   /* 0: the kernels that fold colours, 1: the lean pre-pass kernel (TL_MASK=1) */
+#endif
+#define STAMP_FLUSH if (accumulate && (LEAN ? 1 : 0) == OBIA_STAMP_KIND && (threadIdx.x & 63) == 0 && gtile < 65536) { unsigned long long *st_o = g_tl + ((size_t)gtile * 4 + (threadIdx.x >> 6)) * 24; for (int st_i = 0; st_i < 12; ++st_i) st_o[st_i] = st_acc[st_i]; st_o[12] = st_t0; st_o[13] = clock64(); st_o[14] = st_r0; st_o[15] = __builtin_amdgcn_s_memrealtime(); for (int st_i = 0; st_i < 6; ++st_i) st_o[16 + st_i] = st_cnt[st_i]; }
 #else
 #define STAMP_DECL
 #define STAMP(i)
