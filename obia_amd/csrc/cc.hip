@@ -21,6 +21,8 @@
 // neighbours are classified by root order only).
 #include "slic.hpp"
 
+#include <cstdlib>
+
 namespace obia {
 
 // dense pixel index -> problem (binary search on pix_off; used on roots / small components only)
@@ -516,11 +518,12 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
 // component was labelled before this BFS started: a surviving component as soon as the scan reached its
 // first pixel (root < start); a small component once one of its own BFS attempts found a labelled
 // neighbour (settle < start; a small component that finds none is written back as 0 == unset when
-// start_label is 1).  Returns the last labelled neighbour met.
+// start_label is 1).  Returns the last labelled neighbour met; *min_since = the earliest time at which any
+// neighbouring component is labelled (INT_MAX: never / no neighbour).
 __device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict__ newlab,
                           const int *settle, int r, int start, int mark, int H, int W, int base,
-                          int *__restrict__ q, int32_t *__restrict__ out, int *n_out) {
-    int head = 0, tail = 1, adjacent = -1;
+                          int *__restrict__ q, int32_t *__restrict__ out, int *n_out, int *min_since) {
+    int head = 0, tail = 1, adjacent = -1, ms = 0x7fffffff;
     q[0] = start;
     out[start] = mark;
     while (head < tail) {
@@ -538,21 +541,28 @@ __device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict_
             } else if (rn >= 0) {
                 const int nl = newlab[rn];
                 const int since = (nl >= 0) ? rn : settle[-nl - 2];
+                ms = since < ms ? since : ms;
                 if (since < start) adjacent = nb;     // the LAST labelled neighbour met wins
             }
         }
     }
     *n_out = tail;
+    *min_since = ms;
     return adjacent;
 }
 
 // One lane replays the reference's treatment of one small component: BFS from its first pixel; if no
 // labelled neighbour is found and start_label is 1 the component is written back as 0 (== unset), the
-// raster scan meets it again at its next pixel and the BFS is replayed from there.  settle_out[s] = start
-// pixel of the attempt that found a neighbour (INT_MAX if none), target[s] = that neighbour pixel.
+// raster scan meets it again at its next pixel and the BFS is replayed from there -- and so on, pixel by pixel in raster order,
+// until an attempt meets a labelled neighbour.  An attempt at pixel p succeeds exactly when some neighbouring component is
+// labelled before p, i.e. when p > m = the earliest labelling time among the neighbours (the first BFS has met them all): the
+// successful attempt is the one at the first pixel of the component after m -- found by one pass over the component's pixels,
+// then replayed once for its `adjacent` (round 2 replayed every failed attempt and sorted the pixels by insertion: quadratic in
+// the component's size, which is unbounded through the stage-level entry point).
+// settle_out[s] = start pixel of the attempt that found a neighbour (INT_MAX if none), target[s] = that neighbour pixel.
 // `out` doubles as the visited map (rewritten by the final relabel pass).
-// The settle times are the least fixed point of a monotone map (a neighbour that settles later can only make this component
-// settle later), iterated IN PLACE from the optimistic start: a round evaluates a work list -- every small component in round 0,
+// The settle times are the fixed point of a monotone map (a neighbour that settles later can only make this component
+// settle later), iterated IN PLACE from one side on a work list -- every small component in round 0,
 // afterwards the small neighbours of the components whose settle time moved in the round before (a component meets all its
 // neighbours in its own BFS, adjacency is symmetric, so the one that moves enqueues those that depend on it; `tag` keeps a
 // component from being enqueued twice in a round).  Reads of a neighbour's time may be stale inside a round: every value read
@@ -574,23 +584,22 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__res
     const CcProblem P = probs[find_prob(probs, nprob, r)];
     const int H = P.H, W = P.W, base = (int)P.pix_off;
     int *q = queue + small_qoff[s];
-    int csize = 0;
+    int csize = 0, m = 0x7fffffff;
     int start = r;
-    int adjacent = replay_bfs(parent, newlab, settle, r, r, -(s + 2), H, W, base, q, out, &csize);
+    int adjacent = replay_bfs(parent, newlab, settle, r, r, -(s + 2), H, W, base, q, out, &csize, &m);
     if (adjacent < 0 && start_label == 1) {
         start = 0x7fffffff;
-        for (int a = 1; a < csize && adjacent < 0; ++a) {
-            for (int i = 1; i < csize; ++i) {   // insertion sort: raster order of the component's pixels
-                const int v = q[i];
-                int j = i - 1;
-                while (j >= 0 && q[j] > v) { q[j + 1] = q[j]; --j; }
-                q[j + 1] = v;
+        if (m != 0x7fffffff) {
+            int st = 0x7fffffff;                         // the first pixel of the component after m, in raster order
+            for (int i = 0; i < csize; ++i) { const int p = q[i]; if (p > m && p < st) st = p; }
+            if (st != 0x7fffffff) {
+                for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the first attempt
+                int n2 = 0, m2 = 0;
+                adjacent = replay_bfs(parent, newlab, settle, r, st, -(s + 2), H, W, base, q, out, &n2, &m2);
+                // (a neighbour's time may have moved between the two walks -- another lane of this round: whatever is read lies
+                // between the start and the fixed point, and this component is evaluated again when a neighbour moved)
+                start = adjacent >= 0 ? st : 0x7fffffff;
             }
-            const int st = q[a];
-            for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the last attempt
-            int n2 = 0;
-            adjacent = replay_bfs(parent, newlab, settle, r, st, -(s + 2), H, W, base, q, out, &n2);
-            if (adjacent >= 0) start = st;
         }
     }
     for (int i = 0; i < csize; ++i) out[q[i]] = 0;
@@ -616,9 +625,10 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__res
     }
 }
 
-__global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_small, int *__restrict__ settle) {
+// from_above = 0: the optimistic start (every small component labelled at its first pixel); 1: the pessimistic one (never)
+__global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_small, int *__restrict__ settle, int from_above) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n_small) settle[s] = small_list[s];
+    if (s < n_small) settle[s] = from_above ? 0x7fffffff : small_list[s];
 }
 
 // final labels: survivors get rank + start_label; small components follow their adjacency chain
@@ -724,32 +734,48 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         int *settle = A.get<int>(n_small), *work_a = A.get<int>(n_small), *work_b = A.get<int>(n_small), *tag = A.get<int>(n_small);
         if (!settle || !work_a || !work_b || !tag) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
-        OBIA_HIP_TRY(hipMemsetAsync(tag, 0, sizeof(int) * (size_t)n_small, ctx->stream));
-        hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle);
-        // optimistic start (every small component labelled at its first pixel), then rounds on a work list until no settle
-        // time moves (cc_small_bfs_kernel); one round settles everything unless small components that find no labelled
-        // neighbour touch each other.
-        // (settle times only move forward, and a component's settle time is one of its own pixels or "never": at most
-        // small_px + 1 rounds move something.  Usually one to three; a handful of small components that only touch each other can
-        // need more rounds than there are components -- found by tests/test_gpu_tiling_random.py -- so the bound is the pixel
-        // count, not the component count.  Never cut short: an unconverged round would write label 0)
+        // The settle times solve  t(S) = first pixel of S after min over its neighbours N of t(N)  (t(N) = first pixel of N for a
+        // surviving N; "never" when S has no later pixel).  A time is decided by strictly EARLIER times, so the system has exactly
+        // one solution, and a monotone iteration reaches it from either side:
+        //   from below (optimistic: every small component labelled at its first pixel) -- one round when small components sit
+        //     between surviving ones, which is what a SLIC sweep leaves; but two small components that only see each other
+        //     leapfrog one pixel per round, and a map in which nearly every component is small needs thousands of rounds
+        //     (8.4 s per step of `bench.py --bands 3` in round 2);
+        //   from above (pessimistic: never) -- a round carries the labels one component further away from the surviving
+        //     components: a few rounds more than from below in the SLIC regime, a few dozen where from below needs thousands,
+        //     none at all where nothing survives (numpy model, profiles/r03_notes.md: 1165 -> 1, 856 -> 25 rounds).
+        // So: from below for a few rounds; if that has not converged, start again from above (also at once when small components
+        // outnumber the surviving ones eight to one).  Work list as before: round 0 evaluates every small component, a later round
+        // the small neighbours of the components whose time moved; reads of a neighbour's time may be stale inside a round (every
+        // value read lies between the start and the solution); never cut short: an unconverged round would write label 0.
+        constexpr int ROUNDS_FROM_BELOW = 5;
         bool converged = false;
-        int n_items = n_small;
-        const int *work_in = nullptr;
-        for (long long round = 0; round <= (long long)small_px + 2; ++round) {
-            OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
-                               small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
-                               counters + 5, tag, (int)(round & 0x3fffffff));
-            int n_next = 0;
-            OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
-            if (n_next == 0) { converged = true; break; }
-            work_in = work_a;
-            std::swap(work_a, work_b);
-            n_items = n_next;
+        for (int side = (n_small > 8 * (long long)n_surv ? 1 : 0); side < 2 && !converged; ++side) {
+            OBIA_HIP_TRY(hipMemsetAsync(tag, 0, sizeof(int) * (size_t)n_small, ctx->stream));
+            hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle, side);
+            int n_items = n_small;
+            const int *work_in = nullptr;
+            // (times only move one way and a component's time is one of its own pixels or "never": at most small_px + 1 rounds
+            // move something -- the bound of the second side)
+            const long long max_rounds = side == 0 ? ROUNDS_FROM_BELOW : (long long)small_px + 2;
+            for (long long round = 0; round <= max_rounds; ++round) {
+                if (std::getenv("OBIA_DEBUG_CC")) fprintf(stderr, "[obia cc]   side %d round %lld: %d items\n", side, round, n_items);
+                OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
+                hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
+                                   small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
+                                   counters + 5, tag, (int)(round & 0x3fffffff));
+                int n_next = 0;
+                OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
+                if (n_next == 0) { converged = true; break; }
+                work_in = work_a;
+                std::swap(work_a, work_b);
+                n_items = n_next;
+            }
         }
         if (!converged) { set_error("connectivity enforcement: settle rounds did not converge (%d small components)", n_small); return OBIA_E_INVALID; }
     }
+    if (std::getenv("OBIA_DEBUG_CC"))   // developer aid: the regime of this batch
+        fprintf(stderr, "[obia cc] %lld px, %d problems: %d surviving, %d small components (%d px)\n", n, np, n_surv, n_small, small_px);
     debug_sync(ctx, "cc: rank apply + small components");
     hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
                        mask_label, n_small + 1, labels_out);

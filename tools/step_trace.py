@@ -10,7 +10,7 @@ from obia_amd.statistics import zonal_stats
 from obia_amd.tiling import create_tiled_segments
 S = int(os.environ.get("OBIA_TRACE_SIZE", "16384"))
 dev = torch.device("cuda", 0)
-img = synth_raster(S, S, 8, 0, dev)
+img = synth_raster(S, S, int(os.environ.get("OBIA_TRACE_BANDS", "8")), 0, dev)
 mask = torch.ones((S, S), dtype=torch.uint8, device=dev)
 ctx = _lib.Context(0)
 kw = dict(tile_size=2048, buffer=64, crown_radius=5, pixel_size=(0.5, 0.5), compactness=float(os.environ.get("OBIA_TRACE_COMPACTNESS", "10")), ctx=ctx)
