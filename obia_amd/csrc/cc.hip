@@ -569,16 +569,15 @@ __device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict_
 // lies between the start and the fixed point, a component whose neighbour moved is evaluated again in the next round on values
 // at least as new as the end of this one, and the rounds end when nothing moved -- the same fixed point as synchronous (Jacobi)
 // rounds over all components, at the cost of the frontier instead of the whole list per round.
-__global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__restrict__ probs, int nprob,
-                                                          const int *__restrict__ parent, const int *__restrict__ newlab,
-                                                          const int *__restrict__ small_list, const int *__restrict__ small_qoff,
-                                                          int start_label, int *__restrict__ settle,
-                                                          int *__restrict__ queue, int32_t *__restrict__ out,
-                                                          int *__restrict__ target, const int *__restrict__ work_in, int n_items,
-                                                          int *__restrict__ work_out, int *__restrict__ work_cnt,
-                                                          int *__restrict__ tag, int round) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
+constexpr int BFS_PUSH = 12;   // list entries a lane collects before it falls back to one atomic per entry
+__device__ int small_component_eval(const CcProblem *__restrict__ probs, int nprob,
+                                    const int *__restrict__ parent, const int *__restrict__ newlab,
+                                    const int *__restrict__ small_list, const int *__restrict__ small_qoff,
+                                    int start_label, int *__restrict__ settle,
+                                    int *__restrict__ queue, int32_t *__restrict__ out,
+                                    int *__restrict__ target, const int *__restrict__ work_in, int i,
+                                    int *__restrict__ work_out, int *__restrict__ work_cnt,
+                                    int *__restrict__ tag, int round, int (*s_push)[BFS_PUSH + 1]) {
     const int s = work_in ? work_in[i] : i;
     const int r = small_list[s];
     const CcProblem P = probs[find_prob(probs, nprob, r)];
@@ -604,25 +603,61 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__res
     }
     for (int i = 0; i < csize; ++i) out[q[i]] = 0;
     target[s] = adjacent;
-    if (settle[s] == start) return;
-    settle[s] = start;
-    // moved: the small components around this one (q holds its pixels) are evaluated again in the next round
-    for (int i = 0; i < csize; ++i) {
-        const int p = q[i];
-        const int y = (p - base) / W, x = (p - base) - y * W;
+    // moved: the small components around this one (q holds its pixels) are evaluated again in the next round.  Their list
+    // indices are collected per lane in LDS first and appended with ONE atomic per wave: every enqueue used to add 1 to the same
+    // global word, and atomics on one word run at a few nanoseconds EACH, device-wide -- 2 M of them were most of the 9 ms a
+    // round over 4 M components took (`bench.py --bands 3`, profiles/r03_notes.md).
+    int npush = 0;
+    if (settle[s] != start) {
+        settle[s] = start;
+        for (int i = 0; i < csize; ++i) {
+            const int p = q[i];
+            const int y = (p - base) / W, x = (p - base) - y * W;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
-            const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
-            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const int rn = parent[base + yy * W + xx];
-            if (rn < 0 || rn == r) continue;
-            const int nl = newlab[rn];
-            if (nl >= 0) continue;
-            const int t = -nl - 2;
-            if (atomicExch(&tag[t], round + 1) != round + 1) work_out[atomicAdd(work_cnt, 1)] = t;
+            for (int d = 0; d < 4; ++d) {
+                const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
+                const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                const int rn = parent[base + yy * W + xx];
+                if (rn < 0 || rn == r) continue;
+                const int nl = newlab[rn];
+                if (nl >= 0) continue;
+                const int t = -nl - 2;
+                if (atomicExch(&tag[t], round + 1) != round + 1) {
+                    if (npush < BFS_PUSH) s_push[threadIdx.x][npush++] = t;
+                    else work_out[atomicAdd(work_cnt, 1)] = t;          // (a lane with more than BFS_PUSH new neighbours: rare)
+                }
+            }
         }
     }
+    return npush;
+}
+
+// (the wave meets again here: one reservation for all its lanes)
+__global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__restrict__ probs, int nprob,
+                                                          const int *__restrict__ parent, const int *__restrict__ newlab,
+                                                          const int *__restrict__ small_list, const int *__restrict__ small_qoff,
+                                                          int start_label, int *__restrict__ settle,
+                                                          int *__restrict__ queue, int32_t *__restrict__ out,
+                                                          int *__restrict__ target, const int *__restrict__ work_in, int n_items,
+                                                          int *__restrict__ work_out, int *__restrict__ work_cnt,
+                                                          int *__restrict__ tag, int round) {
+    __shared__ int s_push[64][BFS_PUSH + 1];   // (+1: the lanes' rows start in different banks)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int npush = 0;
+    if (i < n_items)
+        npush = small_component_eval(probs, nprob, parent, newlab, small_list, small_qoff, start_label, settle, queue, out, target,
+                                     work_in, i, work_out, work_cnt, tag, round, s_push);
+    // inclusive prefix of the lanes' counts, one atomic for the wave
+    int inc = npush;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if ((int)threadIdx.x >= off) inc += v; }
+    const int total = __shfl(inc, 63);
+    if (total == 0) return;
+    int base_slot = 0;
+    if (threadIdx.x == 63) base_slot = atomicAdd(work_cnt, total);
+    base_slot = __shfl(base_slot, 63);
+    for (int j = 0; j < npush; ++j) work_out[base_slot + inc - npush + j] = s_push[threadIdx.x][j];
 }
 
 // from_above = 0: the optimistic start (every small component labelled at its first pixel); 1: the pessimistic one (never)

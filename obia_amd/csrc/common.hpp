@@ -85,6 +85,7 @@ struct obia_ctx {
     static constexpr int MAX_SIDE = 3;
     hipStream_t side[MAX_SIDE] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[MAX_SIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;   // the tiler's white feature pass beside the black sweeps (tiling.hip)
 };
 
 namespace obia {

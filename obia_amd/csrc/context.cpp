@@ -119,6 +119,8 @@ ScopedSpan::~ScopedSpan() {
 int side_streams(obia_ctx *ctx, int n) {
     if (n > obia_ctx::MAX_SIDE) n = obia_ctx::MAX_SIDE;
     if (!ctx->fork_ev) OBIA_HIP_TRY(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    if (!ctx->aux_fork) OBIA_HIP_TRY(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    if (!ctx->aux_join) OBIA_HIP_TRY(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
     for (int i = 0; i < n; ++i) {
         if (!ctx->side[i]) OBIA_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
         if (!ctx->join_ev[i]) OBIA_HIP_TRY(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
@@ -283,6 +285,8 @@ void obia_destroy(obia_ctx *ctx) {
         if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -23,6 +23,7 @@
 #include "slic.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace obia {
 
@@ -301,9 +302,19 @@ struct TileState {
         unsigned *d_keys = nullptr;
         int maxh = 1;
         bool launched = false;
+        bool on_side = false;            // the pass was queued on a side stream (beside the black sweeps): join before it is read
         size_t cursor = 0;               // next window to be consumed by a white batch
     } pf;
 };
+
+// The feature pass of the white tiles (bound by HBM, few vector instructions) runs on a side stream beside the black batch's
+// sweeps, whose first nine launches -- the spatial pre-pass -- are bound by vector issue and move no data: 46.62 / 46.48 ->
+// 46.10 / 46.00 ms per step (two pairs on one box; the pre-pass gives back 0.4 ms of the 2.7 ms hidden).  Round 2 had measured the
+// same idea as a loss on the round-1 kernels.  OBIA_WHITE_FEATURES_BESIDE=0 puts the pass back in line (A/B, debugging).
+static bool white_features_beside() {
+    const char *e = std::getenv("OBIA_WHITE_FEATURES_BESIDE");
+    return e ? atoi(e) != 0 : true;
+}
 
 static int grid_rows(const std::vector<TileWin> &wins) {   // row-walking kernels: one block per row (capped)
     int g = 1;
@@ -312,7 +323,7 @@ static int grid_rows(const std::vector<TileWin> &wins) {   // row-walking kernel
 }
 
 // One batch of tiles: mask -> features -> plan -> sweeps -> connectivity -> scatter.
-static int prefetch_white_launch(obia_ctx *ctx, TileState &S);
+static int prefetch_white_launch(obia_ctx *ctx, TileState &S, bool beside = false);
 
 static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &wins, bool white) {
     const int np = (int)wins.size();
@@ -420,6 +431,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     }
     OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, &nvalid));
     debug_sync(ctx, "tiler: plan_and_seed");
+    if (!white && S.pf.d_feat && !S.pf.launched && white_features_beside()) OBIA_TRY(prefetch_white_launch(ctx, S, true));
     OBIA_TRY(slic_run_sweeps(ctx, b));
     debug_sync(ctx, "tiler: sweeps");
     int n_new = 0;
@@ -563,15 +575,28 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
     return OBIA_OK;
 }
 
-static int prefetch_white_launch(obia_ctx *ctx, TileState &S) {
+static int prefetch_white_launch(obia_ctx *ctx, TileState &S, bool beside) {
     TileState::PreFeat &pf = S.pf;
     if (pf.launched || !pf.d_feat) return OBIA_OK;
     pf.launched = true;
-    ScopedSpan span(ctx, T_FEAT);
     const size_t NP = pf.wins.size();
     const int CP = (S.C + 3) & ~3;
     OBIA_TRY(upload_async(ctx, pf.d_windows, pf.windows.data(), sizeof(SrcWindow) * NP));
     const int to_lab = (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0;
+    if (beside) {
+        // `beside`: on a side stream, forked here and joined in prefetch_white_fetch -- the caller queues the black batch's
+        // spatial pre-pass next, a kernel that is bound by vector issue and moves no data, beside this pass, which is bound by HBM
+        OBIA_TRY(side_streams(ctx, obia_ctx::MAX_SIDE));
+        hipStream_t side = ctx->side[obia_ctx::MAX_SIDE - 1];
+        OBIA_HIP_TRY(hipEventRecord(ctx->aux_fork, ctx->stream));
+        OBIA_HIP_TRY(hipStreamWaitEvent(side, ctx->aux_fork, 0));
+        OBIA_TRY(slic_features_launch(side, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
+                                      (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys, true, pf.d_fbox));
+        OBIA_HIP_TRY(hipEventRecord(ctx->aux_join, side));
+        pf.on_side = true;
+        return OBIA_OK;
+    }
+    ScopedSpan span(ctx, T_FEAT);
     OBIA_TRY(slic_features_launch(ctx->stream, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
                                   (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys, true, pf.d_fbox));
     return OBIA_OK;
@@ -580,6 +605,7 @@ static int prefetch_white_launch(obia_ctx *ctx, TileState &S) {
 static int prefetch_white_fetch(obia_ctx *ctx, TileState &S) {
     if (!S.pf.d_feat) return OBIA_OK;
     OBIA_TRY(prefetch_white_launch(ctx, S));
+    if (S.pf.on_side) { OBIA_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0)); S.pf.on_side = false; }
     OBIA_TRY(read_back(ctx, S.pf.host.data(), S.pf.d_keys, S.pf.host.size() * sizeof(unsigned)));
     S.pf.ready = true;
     S.pf.cursor = 0;
