@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void features_planes_kernel(const float *__res
         }
         float4 *dst = planes + ((long long)q * XB + (x >> 4)) * (CP * 16) + (x & 15);
 #pragma unroll
-        for (int c = 0; c < CP; ++c) dst[c * 16] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+        for (int c = 0; c < CP; ++c)
+            if (c < C) dst[c * 16] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);   // (the planes of padded channels are neither written nor read)
     };
     if (!BOX) {
         for (int q = blockIdx.x; q < QH; q += gridDim.x)

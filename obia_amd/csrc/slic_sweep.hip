@@ -251,7 +251,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                           const uint8_t *__restrict__ mask, const float *__restrict__ cent,
                           const int *__restrict__ head, int32_t *__restrict__ labels,
                           unsigned long long *__restrict__ acc, int RQ, int accumulate, int accum_color, int start_label,
-                          float fs, int store_labels, int *__restrict__ orphan_flag, int sweep_id) {
+                          float fs, int store_labels, int *__restrict__ orphan_flag, int sweep_id, int nch) {
     constexpr int RS = CENT_REC + CP;
     const float w = P.spatial_w;
     for (int i = threadIdx.x; i < SWEEP_TW * SWEEP_TH; i += NT) {
@@ -261,7 +261,7 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
         if (MASKED && mask[pix] == 0) { labels[pix] = start_label - 1; continue; }
         float f[CP];
 #pragma unroll
-        for (int ch = 0; ch < CP; ++ch) f[ch] = feat_at(feat, P, CP, y, x, ch);
+        for (int ch = 0; ch < CP; ++ch) f[ch] = ch < nch ? feat_at(feat, P, CP, y, x, ch) : 0.0f;   // (padded planes are not written)
         int by_lo = (y - 2 * P.sy - 2) / P.sy; if (y - 2 * P.sy - 2 < 0) by_lo = 0;
         int by_hi = (y + 2 * P.sy + 2) / P.sy; if (by_hi > P.ncy - 1) by_hi = P.ncy - 1;
         int bx_lo = (x - 2 * P.sx - 2) / P.sx; if (x - 2 * P.sx - 2 < 0) bx_lo = 0;
@@ -317,7 +317,11 @@ __device__ __forceinline__ void slic_assign_body(
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
-    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base) {
+    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg) {
+    // channels that exist: a compile-time constant in the variants compiled per padding (NCH < CP), the launch argument in the
+    // others (NCH == CP: the last pre-pass sweep, SLIC-zero, the fixed-point variant).  The planes of the padded channels are NOT
+    // written by the feature pass since round 3 (nine bands: 36 instead of 48 bytes per pixel): nobody may read them.
+    const int nch_rt = (NCH < CP) ? NCH : nch_arg;
     // COLLB (low compactness): the scoring adds a lower bound of the COLOUR term to the spatial one -- the distance of the
     // candidate's colour to the box of the footprint's features (slic.hpp: feat_boxes) -- and the visits drop from 13 to 7 per
     // footprint at compactness 0.25.  Valid because every step is monotone: |f - c| >= max(lo - c, c - hi, 0) per channel for
@@ -439,7 +443,7 @@ __device__ __forceinline__ void slic_assign_body(
                                      ? ((unsigned)(lane_o >> 4) * (unsigned)((LEAN ? 0 : CP) * 16 * P.XB) + (unsigned)(lane_o & 15)) * 16u : 0u;
 #pragma unroll
             for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) {
-                if (ch >= NCH) { f2[ch][0] = splat(0.0f); f2[ch][1] = splat(0.0f); continue; }   // padded channel: zeros, not read
+                if (ch >= nch_rt) { f2[ch][0] = splat(0.0f); f2[ch][1] = splat(0.0f); continue; }   // padded channel: zeros, not read (wave-uniform)
                 const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pb + ch * 16) + (size_t)fob);
                 f2[ch][0] = (v2f){t.x, t.y};
                 f2[ch][1] = (v2f){t.z, t.w};
@@ -539,7 +543,7 @@ __device__ __forceinline__ void slic_assign_body(
     const int nc = s_cnt;
     if (nc > MAXC) {   // wave-uniform (whole workgroup)
         slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
-                                                      accum_color, start_label, fs, store_labels, orphan_flag, sweep_id);
+                                                      accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
         return;
     }
     auto do_sort = [&]() {
@@ -945,7 +949,7 @@ __device__ __forceinline__ void slic_assign_body(
             if (prev < start_label) continue;
             float one[CP];
 #pragma unroll
-            for (int ch = 0; ch < CP; ++ch) one[ch] = accum_color ? feat_at(feat, P, CP, y, x, ch) : 0.0f;
+            for (int ch = 0; ch < CP; ++ch) one[ch] = (accum_color && ch < nch_rt) ? feat_at(feat, P, CP, y, x, ch) : 0.0f;
             global_accumulate<CP>(acc, RQ, prev - start_label + P.cent_off, (unsigned)y, (unsigned)x, one, fs);
         }
     }
@@ -984,10 +988,10 @@ __device__ __forceinline__ void slic_assign_body(
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
-        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base
+        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg
 #define OBIA_ASSIGN_ARGS                                                                                               \
     probs, feat, mask, cent, head, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base, nch_arg
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, int NCH = CP>
@@ -1019,7 +1023,7 @@ extern "C" void obia_debug_timeline(unsigned long long *out, int nwaves) {   // 
 template <int CP, bool MASKED>
 __global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__restrict__ probs, const float *__restrict__ feat,
                                                            const uint8_t *__restrict__ mask, const int32_t *__restrict__ labels,
-                                                           float *__restrict__ cent, int start_label) {
+                                                           float *__restrict__ cent, int start_label, int nch) {
     constexpr int RS = CENT_REC + CP;
     const SlicProblem P = probs[blockIdx.y];
     for (int y = blockIdx.x; y < P.H; y += gridDim.x)
@@ -1033,6 +1037,7 @@ __global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__
             float dc = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < CP; ++ch) {
+                if (ch >= nch) break;   // (padded channels: 0 - 0)
                 const float t = feat_at(feat, P, CP, y, x, ch) - rec[CENT_REC + ch];
                 dc += t * t;
             }
@@ -1064,7 +1069,7 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     hipExtLaunchKernelGGL(HIP_KERNEL_NAME(__VA_ARGS__), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
                           b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels, b.start_label,      \
                           b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter,          \
-                          b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0)
+                          b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0, b.C)
     // channels that exist: C of the CP = 4 * ceil(C / 4) the planes and records hold.  The two kernels that run 9 of every 10
     // sweeps come in a variant per padding (slic_assign_body: NCH); the others treat the padded channels like real ones.
     const int pad = CP - b.C;
@@ -1251,9 +1256,9 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
 #define LAUNCH_MAXDIST(CPV)                                                                                           \
     do {                                                                                                              \
         if (b.masked) hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_maxdist_kernel<CPV, true>), zg, dim3(256), 0, ctx->stream, b.d_probs, \
-                                         b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label);                   \
+                                         b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label, b.C);            \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_maxdist_kernel<CPV, false>), zg, dim3(256), 0, ctx->stream, b.d_probs, \
-                                b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label);                            \
+                                b.d_feat, b.d_mask, b.d_labels, b.d_cent, b.start_label, b.C);                     \
     } while (0)
                     switch (b.CP) {
                         case 4: LAUNCH_MAXDIST(4); break;

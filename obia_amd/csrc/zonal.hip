@@ -18,6 +18,9 @@ namespace obia {
 constexpr int Z_TILE = 64, Z_SLOTS = 64, Z_MAXB = 16, Z_ROWS = ZR;
 
 struct BandList { int n; int identity; int b[Z_MAXB]; };   // identity: b[i] == i for every i < n
+// four consecutive bands of one pixel: 16 bytes at a 4-byte aligned address when the band count is not a multiple of four (the
+// author's rasters have nine) -- gfx950 loads a dwordx4 from any dword address, the type only tells the compiler so
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 
 __device__ __forceinline__ unsigned zkey(float f) {
     unsigned b = __float_as_uint(f);
@@ -61,13 +64,13 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
     const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
     const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
     const int x = tx0 + tid / LPP, q = tid % LPP;       // column, band quad
-    const bool vec = (C % 4 == 0) && (nb == C) && bl.identity;   // all bands in order: one float4 per lane and row
+    const int nbq = min(4, max(0, nb - 4 * q));         // bands of this lane's quad that exist
+    const bool vec = (nb == C) && bl.identity && nbq == 4;   // all bands in order and a full quad: one 16-byte load per lane and row
     const bool col_ok = x < W;
     int bsel[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)   // constant indices only: the band list stays in scalar registers
         bsel[b] = (q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b];
-    const int nbq = min(4, max(0, nb - 4 * q));         // bands of this lane's quad that exist
 
     int c_lab = -2, c_slot = -1;                        // one-entry cache of the last label -> slot lookup
     auto find_slot = [&](int l) -> int {
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
                 if (l < 0 || l >= n_labels) l = -1;
                 if (l >= 0 && nbq > 0) {
                     const float *px = raw + pix * C;
-                    if (vec) v = reinterpret_cast<const float4 *>(px)[q];
+                    if (vec) { const f4u t = *reinterpret_cast<const f4u *>(px + 4 * q); v = make_float4(t.x, t.y, t.z, t.w); }
                     else {
                         v.x = px[bsel[0]];
                         if (nbq > 1) v.y = px[bsel[1]];
@@ -258,12 +261,12 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
     const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
     const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
     const int x = tx0 + tid / LPP, q = tid % LPP;
-    const bool vec = (C % 4 == 0) && (nb == C) && bl.identity;
+    const int nbq = min(4, max(0, nb - 4 * q));
+    const bool vec = (nb == C) && bl.identity && nbq == 4;
     const bool col_ok = x < W;
     int bsel[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) bsel[b] = (q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b];
-    const int nbq = min(4, max(0, nb - 4 * q));
 
     int rl = -1;
     unsigned rn[4];
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
                 if (l < 0 || l >= n_labels) l = -1;
                 if (l >= 0 && nbq > 0) {
                     const float *px = raw + pix * C;
-                    if (vec) v = reinterpret_cast<const float4 *>(px)[q];
+                    if (vec) { const f4u t = *reinterpret_cast<const f4u *>(px + 4 * q); v = make_float4(t.x, t.y, t.z, t.w); }
                     else {
                         v.x = px[bsel[0]];
                         if (nbq > 1) v.y = px[bsel[1]];
@@ -426,6 +429,7 @@ int zonal_moments_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, in
                        labels, H, W, C, bl, n_labels, start_label, mean, g_n, g_s2, g_s3, g_s4)
     if (bl.n <= 4) LAUNCH_ZM(4);
     else if (bl.n <= 8) LAUNCH_ZM(8);
+    else if (bl.n <= 12) LAUNCH_ZM(12);
     else LAUNCH_ZM(16);
 #undef LAUNCH_ZM
     int ib = cdiv((long long)nlb, 256);
@@ -473,6 +477,7 @@ int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int 
                        bl, n_labels, start_label, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx)
     if (bl.n <= 4) LAUNCH_ZONAL(4);
     else if (bl.n <= 8) LAUNCH_ZONAL(8);
+    else if (bl.n <= 12) LAUNCH_ZONAL(12);   // (nine bands -- the author's rasters -- ran as sixteen until round 3: a quarter of the lanes idle)
     else LAUNCH_ZONAL(16);
 #undef LAUNCH_ZONAL
     hipLaunchKernelGGL(zonal_finalize_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx,
