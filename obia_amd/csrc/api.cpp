@@ -53,7 +53,7 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.d_mask = const_cast<uint8_t *>(mask);
     const int to_lab = (C == 3 && p->convert2lab != 0) ? 1 : 0;
     const float ratio = (float)(1.0 / p->compactness);   // `image * ratio`: float32 array times Python float
-    b.col_lb = slic_use_colour_bound(ratio) && !b.slic_zero && !b.exit_on_fixed_point;
+    b.col_lb = slic_use_colour_bound(ratio, to_lab != 0) && !b.slic_zero && !b.exit_on_fixed_point;
     if (b.col_lb) {
         b.d_fbox = A.get<float>((size_t)feat_boxes(H, W) * 2 * b.CP);
         if (!b.d_fbox) return OBIA_E_NOMEM;

@@ -513,36 +513,81 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
     }
 }
 
-// BFS of the reference over the component rooted at r, started at `start`; neighbour order
+// code[p]: which component pixel p belongs to, in the form the replay needs -- -1 masked, r >= 0 for a pixel of the SURVIVING
+// component rooted at r (r is also the time at which that component is labelled), -(s + 2) for a pixel of small component s.  One
+// dense pass; the replay then reads ONE word per neighbour where it used to chase parent[] -> newlab[] (two dependent gathers).
+__global__ __launch_bounds__(256) void cc_code_kernel(const int *__restrict__ parent, const int *__restrict__ newlab, long long n,
+                                                      int *__restrict__ code) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = parent[i];
+        int c = -1;
+        if (r >= 0) { const int nl = newlab[r]; c = nl >= 0 ? r : nl; }
+        code[i] = c;
+    }
+}
+
+// BFS of the reference over small component s (code mine = -(s + 2)), started at `start`; neighbour order
 // (x+1, x-1, y+1, y-1).  A neighbour pixel of another component counts as "already labelled" when that
 // component was labelled before this BFS started: a surviving component as soon as the scan reached its
 // first pixel (root < start); a small component once one of its own BFS attempts found a labelled
 // neighbour (settle < start; a small component that finds none is written back as 0 == unset when
 // start_label is 1).  Returns the last labelled neighbour met; *min_since = the earliest time at which any
 // neighbouring component is labelled (INT_MAX: never / no neighbour).
-__device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict__ newlab,
-                          const int *settle, int r, int start, int mark, int H, int W, int base,
-                          int *__restrict__ q, int32_t *__restrict__ out, int *n_out, int *min_since) {
+// The kernel is bound by the latency of its gathers (1 555 load instructions per wave, 10 % of the wave cycles spent on anything
+// else: profiles/r03_notes.md), so a popped pixel issues the four code words of its neighbours TOGETHER, then -- together again --
+// what each of them needs next (the visited mark of an own pixel, the settle time of a small neighbour): two round trips per
+// pixel where the branchy form took up to twelve.  NBR (nullable): the small neighbours met, for the caller's enqueue.
+// CODE = false: no code[] array (few small components: the dense pass would cost more than it saves); the word is derived from
+// parent[] and newlab[] -- two dependent gathers, still issued for the four neighbours together.
+struct NbrList { int *buf; int n; int cap; bool overflow; };
+template <bool CODE>
+__device__ int replay_bfs(const int *__restrict__ code, const int *__restrict__ newlab, const int *settle, int mine, int start, int H, int W, int base,
+                          int *__restrict__ q, int32_t *__restrict__ out, int *n_out, int *min_since, NbrList *nbrs) {
     int head = 0, tail = 1, adjacent = -1, ms = 0x7fffffff;
     q[0] = start;
-    out[start] = mark;
+    out[start] = mine;
     while (head < tail) {
         const int p = q[head++];
         const int y = (p - base) / W, x = (p - base) - y * W;
+        int nb[4], c[4], v2[4];
+        bool ok[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
             const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
-            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const int nb = base + yy * W + xx;
-            const int rn = parent[nb];
-            if (rn == r) {
-                if (out[nb] != mark) { out[nb] = mark; q[tail++] = nb; }
-            } else if (rn >= 0) {
-                const int nl = newlab[rn];
-                const int since = (nl >= 0) ? rn : settle[-nl - 2];
+            ok[d] = !(xx < 0 || xx >= W || yy < 0 || yy >= H);
+            nb[d] = ok[d] ? base + yy * W + xx : p;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) c[d] = code[nb[d]];                 // four loads in flight (CODE = false: `code` is parent[])
+        if (!CODE) {
+            int nl[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) nl[d] = newlab[c[d] >= 0 ? c[d] : 0];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) c[d] = c[d] < 0 ? -1 : (nl[d] >= 0 ? c[d] : nl[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {                                   // ... and the four that depend on them
+            const bool own = c[d] == mine;
+            const int *src = own ? (const int *)out + nb[d] : settle + ((!own && c[d] <= -2) ? -c[d] - 2 : 0);
+            v2[d] = (ok[d] && (own || c[d] <= -2)) ? *src : 0;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {                                   // the reference's order
+            if (!ok[d]) continue;
+            if (c[d] == mine) {
+                if (v2[d] != mine) { out[nb[d]] = mine; q[tail++] = nb[d]; }
+            } else if (c[d] != -1) {
+                const int since = c[d] >= 0 ? c[d] : v2[d];
                 ms = since < ms ? since : ms;
-                if (since < start) adjacent = nb;     // the LAST labelled neighbour met wins
+                if (since < start) adjacent = nb[d];                    // the LAST labelled neighbour met wins
+                if (nbrs && c[d] <= -2) {                               // a small neighbour: remembered for the enqueue
+                    const int t = -c[d] - 2;
+                    if (nbrs->n == 0 || nbrs->buf[nbrs->n - 1] != t) {
+                        if (nbrs->n < nbrs->cap) nbrs->buf[nbrs->n++] = t; else nbrs->overflow = true;
+                    }
+                }
             }
         }
     }
@@ -570,8 +615,9 @@ __device__ int replay_bfs(const int *__restrict__ parent, const int *__restrict_
 // at least as new as the end of this one, and the rounds end when nothing moved -- the same fixed point as synchronous (Jacobi)
 // rounds over all components, at the cost of the frontier instead of the whole list per round.
 constexpr int BFS_PUSH = 12;   // list entries a lane collects before it falls back to one atomic per entry
+template <bool CODE>
 __device__ int small_component_eval(const CcProblem *__restrict__ probs, int nprob,
-                                    const int *__restrict__ parent, const int *__restrict__ newlab,
+                                    const int *__restrict__ code, const int *__restrict__ newlab,
                                     const int *__restrict__ small_list, const int *__restrict__ small_qoff,
                                     int start_label, int *__restrict__ settle,
                                     int *__restrict__ queue, int32_t *__restrict__ out,
@@ -582,10 +628,12 @@ __device__ int small_component_eval(const CcProblem *__restrict__ probs, int npr
     const int r = small_list[s];
     const CcProblem P = probs[find_prob(probs, nprob, r)];
     const int H = P.H, W = P.W, base = (int)P.pix_off;
+    const int mine = -(s + 2);
     int *q = queue + small_qoff[s];
     int csize = 0, m = 0x7fffffff;
     int start = r;
-    int adjacent = replay_bfs(parent, newlab, settle, r, r, -(s + 2), H, W, base, q, out, &csize, &m);
+    NbrList nbrs{&s_push[threadIdx.x][0], 0, BFS_PUSH, false};   // the small neighbours met by the first walk (it meets them all)
+    int adjacent = replay_bfs<CODE>(code, newlab, settle, mine, r, H, W, base, q, out, &csize, &m, &nbrs);
     if (adjacent < 0 && start_label == 1) {
         start = 0x7fffffff;
         if (m != 0x7fffffff) {
@@ -594,7 +642,7 @@ __device__ int small_component_eval(const CcProblem *__restrict__ probs, int npr
             if (st != 0x7fffffff) {
                 for (int i = 0; i < csize; ++i) out[q[i]] = 0;   // clear the visited marks of the first attempt
                 int n2 = 0, m2 = 0;
-                adjacent = replay_bfs(parent, newlab, settle, r, st, -(s + 2), H, W, base, q, out, &n2, &m2);
+                adjacent = replay_bfs<CODE>(code, newlab, settle, mine, st, H, W, base, q, out, &n2, &m2, nullptr);
                 // (a neighbour's time may have moved between the two walks -- another lane of this round: whatever is read lies
                 // between the start and the fixed point, and this component is evaluated again when a neighbour moved)
                 start = adjacent >= 0 ? st : 0x7fffffff;
@@ -603,30 +651,35 @@ __device__ int small_component_eval(const CcProblem *__restrict__ probs, int npr
     }
     for (int i = 0; i < csize; ++i) out[q[i]] = 0;
     target[s] = adjacent;
-    // moved: the small components around this one (q holds its pixels) are evaluated again in the next round.  Their list
-    // indices are collected per lane in LDS first and appended with ONE atomic per wave: every enqueue used to add 1 to the same
-    // global word, and atomics on one word run at a few nanoseconds EACH, device-wide -- 2 M of them were most of the 9 ms a
-    // round over 4 M components took (`bench.py --bands 3`, profiles/r03_notes.md).
+    // moved: the small components around this one are evaluated again in the next round.  Their list indices are collected per
+    // lane in LDS and appended with ONE atomic per wave: every enqueue used to add 1 to the same global word, and atomics on one
+    // word run at a few nanoseconds EACH, device-wide.  The first walk has met every neighbour: its list (consecutive repeats
+    // dropped, `tag` drops the rest) is the enqueue -- unless it overflowed, then the component's pixels are walked once more.
+    if (settle[s] == start) return 0;
+    settle[s] = start;
     int npush = 0;
-    if (settle[s] != start) {
-        settle[s] = start;
-        for (int i = 0; i < csize; ++i) {
-            const int p = q[i];
-            const int y = (p - base) / W, x = (p - base) - y * W;
+    if (!nbrs.overflow) {
+        for (int j = 0; j < nbrs.n; ++j) {
+            const int t = s_push[threadIdx.x][j];
+            if (atomicExch(&tag[t], round + 1) != round + 1) s_push[threadIdx.x][npush++] = t;   // (npush <= j: in place)
+        }
+        return npush;
+    }
+    for (int i = 0; i < csize; ++i) {
+        const int p = q[i];
+        const int y = (p - base) / W, x = (p - base) - y * W;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
-                const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
-                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                const int rn = parent[base + yy * W + xx];
-                if (rn < 0 || rn == r) continue;
-                const int nl = newlab[rn];
-                if (nl >= 0) continue;
-                const int t = -nl - 2;
-                if (atomicExch(&tag[t], round + 1) != round + 1) {
-                    if (npush < BFS_PUSH) s_push[threadIdx.x][npush++] = t;
-                    else work_out[atomicAdd(work_cnt, 1)] = t;          // (a lane with more than BFS_PUSH new neighbours: rare)
-                }
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
+            const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            int c = code[base + yy * W + xx];
+            if (!CODE) c = c < 0 ? -1 : (newlab[c] >= 0 ? c : newlab[c]);
+            if (c > -2 || c == mine) continue;
+            const int t = -c - 2;
+            if (atomicExch(&tag[t], round + 1) != round + 1) {
+                if (npush < BFS_PUSH) s_push[threadIdx.x][npush++] = t;
+                else work_out[atomicAdd(work_cnt, 1)] = t;          // (more than BFS_PUSH new neighbours)
             }
         }
     }
@@ -634,8 +687,9 @@ __device__ int small_component_eval(const CcProblem *__restrict__ probs, int npr
 }
 
 // (the wave meets again here: one reservation for all its lanes)
+template <bool CODE>
 __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__restrict__ probs, int nprob,
-                                                          const int *__restrict__ parent, const int *__restrict__ newlab,
+                                                          const int *__restrict__ code, const int *__restrict__ newlab,
                                                           const int *__restrict__ small_list, const int *__restrict__ small_qoff,
                                                           int start_label, int *__restrict__ settle,
                                                           int *__restrict__ queue, int32_t *__restrict__ out,
@@ -646,7 +700,7 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int npush = 0;
     if (i < n_items)
-        npush = small_component_eval(probs, nprob, parent, newlab, small_list, small_qoff, start_label, settle, queue, out, target,
+        npush = small_component_eval<CODE>(probs, nprob, code, newlab, small_list, small_qoff, start_label, settle, queue, out, target,
                                      work_in, i, work_out, work_cnt, tag, round, s_push);
     // inclusive prefix of the lanes' counts, one atomic for the wave
     int inc = npush;
@@ -767,8 +821,13 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
                            newlab, small_list, small_qoff, counters, rb);
     if (n_small > 0) {
         int *settle = A.get<int>(n_small), *work_a = A.get<int>(n_small), *work_b = A.get<int>(n_small), *tag = A.get<int>(n_small);
-        if (!settle || !work_a || !work_b || !tag) return OBIA_E_NOMEM;
+        // the dense code[] pass pays when small components are many (one per 64 pixels or more: `bench.py --bands 3` has one per 33,
+        // compactness 0.25 on eight bands one per ~170, where the pass cost 0.5 ms per step more than it saved)
+        const bool use_code = (long long)n_small * 64 >= n;
+        int *code = use_code ? A.get<int>(n) : parent;
+        if (!settle || !work_a || !work_b || !tag || !code) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
+        if (use_code) hipLaunchKernelGGL(cc_code_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, n, code);
         // The settle times solve  t(S) = first pixel of S after min over its neighbours N of t(N)  (t(N) = first pixel of N for a
         // surviving N; "never" when S has no later pixel).  A time is decided by strictly EARLIER times, so the system has exactly
         // one solution, and a monotone iteration reaches it from either side:
@@ -796,9 +855,14 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
             for (long long round = 0; round <= max_rounds; ++round) {
                 if (std::getenv("OBIA_DEBUG_CC")) fprintf(stderr, "[obia cc]   side %d round %lld: %d items\n", side, round, n_items);
                 OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
-                hipLaunchKernelGGL(cc_small_bfs_kernel, dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, parent, newlab,
-                                   small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
-                                   counters + 5, tag, (int)(round & 0x3fffffff));
+                if (use_code)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(cc_small_bfs_kernel<true>), dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, code,
+                                       newlab, small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
+                                       counters + 5, tag, (int)(round & 0x3fffffff));
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(cc_small_bfs_kernel<false>), dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, code,
+                                       newlab, small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
+                                       counters + 5, tag, (int)(round & 0x3fffffff));
                 int n_next = 0;
                 OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
                 if (n_next == 0) { converged = true; break; }

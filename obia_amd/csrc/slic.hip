@@ -350,12 +350,14 @@ __global__ __launch_bounds__(256) void features_planes_kernel(const float *__res
     if ((threadIdx.x & 63) == 0) lazy_atomic_max(maxabs_bits + p, __float_as_uint(local_max));
 }
 
-// The colour-box bound pays when the colour term decides (image ratio = 1 / compactness large): measured break-even near
-// compactness 1 (13.6 -> 7.2 visits per footprint at 0.25, 5.1 -> 4.8 at 1, none at 10).
-bool slic_use_colour_bound(float ratio) {
+// The colour-box bound pays when the colour term decides, i.e. when the features (after `* 1 / compactness`) are large against
+// the spatial term: measured break-even near compactness 1 on [0, 1] features (13.6 -> 7.2 visits per footprint at 0.25,
+// 5.1 -> 4.8 at 1, none at 10).  Lab features span ~100 units where normalised bands span 1: a three-band raster at compactness
+// 10 is as colour-dominated as eight bands at 0.1 (`bench.py --bands 3`: 462 us per sweep launch without the bound).
+bool slic_use_colour_bound(float ratio, bool to_lab) {
     static const char *env = std::getenv("OBIA_COLOUR_BOUND");   // developer switch (A/B timing)
     if (env) return env[0] == '1';
-    return ratio >= 2.0f;
+    return ratio * (to_lab ? 100.0f : 1.0f) >= 2.0f;
 }
 
 __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {

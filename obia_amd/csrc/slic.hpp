@@ -106,8 +106,8 @@ int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *non
                          std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
                           int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
-// Does a batch with this image ratio (1 / compactness) use the colour-box bound?  (OBIA_COLOUR_BOUND=0/1 overrides.)
-bool slic_use_colour_bound(float ratio);
+// Does a batch with this image ratio (1 / compactness; to_lab: the features are Lab, ~100 units wide) use the colour-box bound?  (OBIA_COLOUR_BOUND=0/1 overrides.)
+bool slic_use_colour_bound(float ratio, bool to_lab = false);
 
 // Seeds (grid or masked grid), fills K / steps / bins in b.probs, uploads descriptors.
 // n_segments[p] = requested segments of problem p.

@@ -355,7 +355,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         boff += feat_boxes(wins[p].h, wins[p].w);
     }
     b.total_feat_f4 = foff;
-    b.col_lb = slic_use_colour_bound((float)(1.0 / S.sp.compactness)) && !b.slic_zero && !b.exit_on_fixed_point;
+    b.col_lb = slic_use_colour_bound((float)(1.0 / S.sp.compactness), S.C == 3 && S.sp.convert2lab != 0) && !b.slic_zero && !b.exit_on_fixed_point;
     if (off > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
     b.total_pix = off;
     TileWin *d_wins = A.get<TileWin>(np);
@@ -567,7 +567,7 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
     pf.d_keys = A.get<unsigned>(ntot);
     pf.d_feat = A.get<float>(4 * (size_t)foff);
     if (!pf.d_windows || !pf.d_keys || !pf.d_feat) return OBIA_E_NOMEM;
-    if (slic_use_colour_bound((float)(1.0 / S.sp.compactness)) && !S.sp.slic_zero && !S.sp.exit_on_fixed_point) {
+    if (slic_use_colour_bound((float)(1.0 / S.sp.compactness), S.C == 3 && S.sp.convert2lab != 0) && !S.sp.slic_zero && !S.sp.exit_on_fixed_point) {
         pf.d_fbox = A.get<float>((size_t)boff * 2 * CP);
         if (!pf.d_fbox) return OBIA_E_NOMEM;
     }
