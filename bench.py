@@ -85,9 +85,9 @@ def kernel_source_sha256():
 
 
 def traffic_fields(args, C, world):
-    """roofline.traffic from profiles/r02_traffic.json (written by tools/traffic_json.py from two rocprofv3 --pmc passes of
+    """roofline.traffic from profiles/r03_traffic.json (written by tools/traffic_json.py from two rocprofv3 --pmc passes of
     this workload).  null unless the file was measured on exactly these kernel sources and this workload."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     none = {"traffic": None, "traffic_source": None}
     try:
         with open(path) as fh:
@@ -99,11 +99,11 @@ def traffic_fields(args, C, world):
     same_wl = (world == 1 and args.config == "c3" and wl.get("size") == args.size and wl.get("tile") == args.tile
                and wl.get("buffer") == args.buffer and wl.get("bands") == C and abs(wl.get("compactness", -1) - args.compactness) < 1e-12)
     if not (same_src and same_wl):
-        return dict(none, traffic_source=f"profiles/r02_traffic.json is for other {'sources' if not same_src else 'workload'} "
+        return dict(none, traffic_source=f"profiles/r03_traffic.json is for other {'sources' if not same_src else 'workload'} "
                                          f"(measured at commit {t.get('commit')}): not reported")
     k = t["kernels"]["slic_assign_colour"]
     return {"traffic": int(round(k["bytes_per_launch"])),
-            "traffic_source": f"profiles/r02_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per launch, measured at commit {t.get('commit')} "
+            "traffic_source": f"profiles/r03_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per launch, measured at commit {t.get('commit')} "
                               f"on the same kernel sources ({k['bytes_per_pixel']:.1f} B/pixel vs 36 algorithmic)"}
 
 

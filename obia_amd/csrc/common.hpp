@@ -121,4 +121,15 @@ void debug_sync(obia_ctx *ctx, const char *stage);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Loads of data that ONE workgroup reads ONCE per pass (feature planes in a sweep, the raster in the feature and statistics
+// passes): non-temporal, so the lines do not displace what IS re-read from the caches -- centroid records, bin heads, accumulator
+// lines.  Measured on the colour sweep: 0.2144 -> 0.2065 ms, 0.2143 -> 0.2087 ms per launch (two pairs on one box).
+#if defined(__HIPCC__)
+typedef float obia_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream_f4(const void *p) {
+    const obia_v4f t = __builtin_nontemporal_load(reinterpret_cast<const obia_v4f *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+#endif
+
 }  // namespace obia

@@ -444,7 +444,8 @@ __device__ __forceinline__ void slic_assign_body(
 #pragma unroll
             for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) {
                 if (ch >= nch_rt) { f2[ch][0] = splat(0.0f); f2[ch][1] = splat(0.0f); continue; }   // padded channel: zeros, not read (wave-uniform)
-                const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pb + ch * 16) + (size_t)fob);
+                // (non-temporal: a feature line is read by one wave, once per sweep -- common.hpp: ld_stream_f4)
+                const float4 t = ld_stream_f4(reinterpret_cast<const char *>(pb + ch * 16) + (size_t)fob);
                 f2[ch][0] = (v2f){t.x, t.y};
                 f2[ch][1] = (v2f){t.z, t.w};
             }

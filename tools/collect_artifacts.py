@@ -1,4 +1,4 @@
-"""After `gpurun -- 'bash tools/final_artifacts.sh'`: profiles/r02_traffic.json from the newest counter files, the bench lines and
+"""After `gpurun -- 'bash tools/final_artifacts.sh'`: profiles/r03_traffic.json from the newest counter files, the bench lines and
 the kernel statistics copied under profiles/.   python tools/collect_artifacts.py <commit>"""
 import csv, glob, json, os, shutil, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,10 +8,10 @@ tf, tw = tempfile.mkdtemp(), tempfile.mkdtemp()
 shutil.copy(newest("fa_fetch/*/*_counter_collection.csv"), tf)
 shutil.copy(newest("fa_write/*/*_counter_collection.csv"), tw)
 out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "traffic_json.py"), tf, tw, sys.argv[1]])
-open(os.path.join(root, "profiles", "r02_traffic.json"), "wb").write(out)
+open(os.path.join(root, "profiles", "r03_traffic.json"), "wb").write(out)
 t = json.loads(out)
 print(t["commit"], {k: round(v.get("bytes_per_pixel", 0), 2) for k, v in t["kernels"].items()})
-for src, dst in (("fa_bench.json", "r02_b_bench.json"), ("fa_bench_rocprof.json", "r02_b_bench_under_rocprof.json"), ("fa_bench_c4.json", "r02_b_bench_c4.json")):
+for src, dst in (("fa_bench.json", "r03_bench.json"), ("fa_bench_rocprof.json", "r03_bench_under_rocprof.json"), ("fa_bench_c4.json", "r03_bench_c4.json")):
     b = json.loads(open(os.path.join(go, src)).read().strip().splitlines()[-1])
     r = b["roofline"]
     print(dst, b["value"], b["ms_per_step"], r["avg_launch_ms"], r["frac"], r["traffic"],
@@ -20,4 +20,4 @@ for src, dst in (("fa_bench.json", "r02_b_bench.json"), ("fa_bench_rocprof.json"
 ks = newest("fa_trace/*/*_kernel_stats.csv")
 for row in list(csv.DictReader(open(ks)))[:4]:
     print(row["Name"][:70], row["Calls"], row["AverageNs"])
-shutil.copy(ks, os.path.join(root, "profiles", "r02_b_kernel_stats.csv"))
+shutil.copy(ks, os.path.join(root, "profiles", "r03_kernel_stats.csv"))
