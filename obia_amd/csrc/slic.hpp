@@ -53,8 +53,14 @@ inline long long feat_boxes(int h, int w) { return (long long)(((h + 3) / 4 + 3)
 // step 0 == slice(None).
 void regular_grid_hw(long long H, long long W, long long n, long long out[4]);
 
-constexpr int SWEEP_TW = 64, SWEEP_TH = 64;   // workgroup tile of the sweep kernel (pixels)
-constexpr int SWEEP_MAXC = 96;   // candidate slots of a sweep tile (LDS slots of the sweep kernel)
+#ifndef OBIA_SWEEP_TW
+#define OBIA_SWEEP_TW 64
+#endif
+#ifndef OBIA_SWEEP_MAXC
+#define OBIA_SWEEP_MAXC 96
+#endif
+constexpr int SWEEP_TW = OBIA_SWEEP_TW, SWEEP_TH = 64;   // workgroup tile of the sweep kernel (pixels)
+constexpr int SWEEP_MAXC = OBIA_SWEEP_MAXC;   // candidate slots of a sweep tile (LDS slots of the sweep kernel)
 constexpr int CENT_REC = 8;      // header dwords of a centroid record: cy, cx, y0, y1, x0, x1, k, -
 // Accumulator record of one centroid, 128-byte aligned so a tile's flush touches two 64-B lines:
 //   q[0..CP)  colour sums, 64-bit fixed point     q[CP] = n | (sum_y << 32)     q[CP+1] = sum_x
