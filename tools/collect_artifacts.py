@@ -17,6 +17,9 @@ for src, dst in (("fa_bench.json", "r03_bench.json"), ("fa_bench_rocprof.json", 
     print(dst, b["value"], b["ms_per_step"], r["avg_launch_ms"], r["frac"], r["traffic"],
           {k: (b[k] or {}).get("value") for k in ("with_exit_on_fixed_point", "compactness_0.25", "quickshift", "cpu_baseline")})
     shutil.copy(os.path.join(go, src), os.path.join(root, "profiles", dst))
+for src, dst in (("fa_bench_bands3.json", "r03_bench_bands3.json"), ("fa_step_timeline.txt", "r03_step_timeline.txt")):
+    if os.path.exists(os.path.join(go, src)):
+        shutil.copy(os.path.join(go, src), os.path.join(root, "profiles", dst))
 ks = newest("fa_trace/*/*_kernel_stats.csv")
 for row in list(csv.DictReader(open(ks)))[:4]:
     print(row["Name"][:70], row["Calls"], row["AverageNs"])
