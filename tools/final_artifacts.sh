@@ -4,7 +4,9 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 400 python bench.py > gpurun_out/fa_bench.json 2> gpurun_out/fa_bench.err
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fa_trace -- python3 bench.py --no-cpu > gpurun_out/fa_bench_rocprof.json 2> gpurun_out/fa_rocprof.err
+# (the profiled command is the timed workload alone: with the side legs the statistics would average the colour sweep over the
+# 16384^2 and the 32768^2 rasters, whose launches differ in size)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fa_trace -- python3 bench.py --no-cpu --no-side > gpurun_out/fa_bench_rocprof.json 2> gpurun_out/fa_rocprof.err
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/fa_fetch -- python3 tools/step_trace.py > gpurun_out/fa_f.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/fa_write -- python3 tools/step_trace.py > gpurun_out/fa_w.log 2>&1
 timeout -k 10 400 python bench.py --config c4 --no-cpu --no-side > gpurun_out/fa_bench_c4.json 2> gpurun_out/fa_c4.err
