@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 #include <cstdarg>

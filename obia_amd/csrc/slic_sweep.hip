@@ -288,8 +288,12 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
         int k = bk;
         if (k < 0) {   // `nearest` keeps the previous sweep's value
             if (orphan_needs_repeat(store_labels, sweep_id)) *orphan_flag = 1;   // ... which was not stored: the host repeats the batch with every sweep storing
-            const int prev = labels[pix];
-            if (prev >= start_label) k = prev - start_label + P.cent_off;
+            // (the previous label is in memory only when every sweep stores -- otherwise labels[] holds whatever the arena held, the
+            // flag above has the batch repeated, and this sweep's sums are thrown away with it)
+            if (store_labels == 2) {
+                const int prev = labels[pix];
+                if (prev >= start_label) k = prev - start_label + P.cent_off;
+            }
         } else {
             labels[pix] = k - P.cent_off + start_label;
         }
@@ -941,7 +945,7 @@ __device__ __forceinline__ void slic_assign_body(
 #undef BK_D
     if (!accumulate) { STAMP_FLUSH return; }
     __syncthreads();
-    if (s_uncacheable && store_labels) {   // workgroup-uniform, rare: the orphan pixels of the tile go straight to the global records
+    if (s_uncacheable && store_labels == 2) {   // workgroup-uniform, rare: the orphan pixels of the tile go straight to the global records (their previous labels are in memory only when every sweep stores)
         for (int i = tid; i < SWEEP_TH * SWEEP_TW; i += NT) {
             if (!((s_orph[i >> 5] >> (i & 31)) & 1u)) continue;
             const int y = ty0 + i / SWEEP_TW, x = tx0 + i % SWEEP_TW;
@@ -1123,8 +1127,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, b.d_labels, n, b.start_label - 1);
     };
-    fill_labels();
-    debug_sync(ctx, "sweeps: label fill");
+    // (nearest[:] = start_label - 1 is written further down, and only when some pixel can keep that value)
     if (std::getenv("OBIA_DEBUG_SYNC"))
         for (size_t p = 0; p < b.probs.size(); ++p) {
             const SlicProblem &P = b.probs[p];
@@ -1132,7 +1135,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                     p, P.H, P.W, P.K, P.sy, P.sx, P.ncy, P.ncx, P.cell_off, P.cent_off, P.tiles_y, P.tiles_x, P.tile_off, P.n_valid,
                     b.total_cent, b.total_cells, b.total_tiles_all);
         }
-    if (b.total_tiles <= 0 || b.max_iter <= 0) return OBIA_OK;
+    if (b.total_tiles <= 0 || b.max_iter <= 0) { fill_labels(); return OBIA_OK; }   // no sweep: every pixel keeps the fill value
     // the sweep addresses a footprint's pixels as a 64-bit wave-uniform base plus a 32-bit lane offset (16 rows x W x 64 B)
     for (auto &P : b.probs)
         if (P.W >= (1 << 22)) { set_error("rasters / tile windows wider than 4194303 pixels are not supported (got %d)", P.W); return OBIA_E_UNSUPPORTED; }
@@ -1302,6 +1305,14 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     };
     static const bool env_store_all = std::getenv("OBIA_STORE_ALL_LABELS") != nullptr;   // developer switch (A/B timing)
     const bool store_all = b.exit_on_fixed_point || b.slic_zero || env_store_all;
+    // The fill value survives in exactly one kind of pixel: a valid one that no window reached ("orphan").  When only the last sweep
+    // stores, such a pixel raises the flag and the batch is repeated below (with the fill) -- unless the batch has ONE sweep in all,
+    // where the fill value is what the reference keeps.  Every other pixel is written by the last sweep (masked ones included): the
+    // 1.2 GB fill of a bench batch is skipped on the common path.
+    if (store_all || passes * b.max_iter <= 1) {
+        fill_labels();
+        debug_sync(ctx, "sweeps: label fill");
+    }
     OBIA_TRY(run_all(store_all));
     unsigned long long h[513];
     OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
