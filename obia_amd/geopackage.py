@@ -61,9 +61,13 @@ def gpkg_blob(wkb, srs_id):
     return b"GP" + struct.pack("<BBi4d", 0, 0x03, int(srs_id), minx, maxx, miny, maxy) + bytes(wkb)
 
 
-def write_geopackage(path, wkb_list, columns, table="segments", srs_epsg=None, geometry_type="POLYGON"):
+def write_geopackage(path, wkb_list, columns, table="segments", srs_epsg=None, geometry_type=None, srs_wkt=None):
     """Write one feature table.  ``wkb_list``: WKB bytes per feature; ``columns``: dict name -> sequence (ints or floats)
-    of the same length.  ``srs_epsg``: EPSG code of the coordinates (None: undefined cartesian, srs_id -1)."""
+    of the same length.  ``srs_epsg``: EPSG code of the coordinates (None: undefined cartesian, srs_id -1).
+    ``geometry_type``: the name registered in gpkg_geometry_columns; None = "POLYGON" when every blob is a WKB Polygon,
+    "MULTIPOLYGON" when every blob is a MultiPolygon, "GEOMETRY" for a mix (quickshift labels can come out as MultiPolygons:
+    strict readers reject a POLYGON table that holds one).  ``srs_wkt``: the WKT definition of a non-4326 EPSG code; without it
+    the row says "undefined" and a reader resolves the CRS from organization / organization_coordsys_id (most do)."""
     n = len(wkb_list)
     for k, v in columns.items():
         if len(v) != n:
@@ -92,7 +96,11 @@ def write_geopackage(path, wkb_list, columns, table="segments", srs_epsg=None, g
         cur.executemany("INSERT INTO gpkg_spatial_ref_sys VALUES (?,?,?,?,?,?)", _SRS_ROWS)
         if srs_id not in (-1, 0, 4326):
             cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES (?,?,?,?,?,?)",
-                        (f"EPSG:{srs_id}", srs_id, "EPSG", srs_id, "undefined", "definition not carried by the writer"))
+                        (f"EPSG:{srs_id}", srs_id, "EPSG", srs_id, srs_wkt or "undefined",
+                         None if srs_wkt else "definition not carried by the writer: resolve by organization / organization_coordsys_id"))
+        if geometry_type is None:
+            kinds = {struct.unpack_from("<I", w, 1)[0] & 0xff for w in wkb_list}
+            geometry_type = "POLYGON" if kinds <= {3} else ("MULTIPOLYGON" if kinds == {6} else "GEOMETRY")
         names = list(columns)
         types = {}
         for k in names:

@@ -146,7 +146,17 @@ def test_geopackage_round_trip(tmp_path):
     blob = con.execute("SELECT geom FROM segments WHERE fid = 2").fetchone()[0]
     assert blob[:2] == b"GP" and struct.unpack_from("<i", blob, 4)[0] == 32610
     assert struct.unpack_from("<4d", blob, 8) == (20.0, 32.0, 0.0, 7.0)
+    # the registered geometry type follows the blobs (a POLYGON table that holds a MultiPolygon is rejected by
+    # strict readers): a mix is GEOMETRY, polygons only POLYGON, multipolygons only MULTIPOLYGON; a WKT definition is carried
+    assert con.execute("SELECT geometry_type_name FROM gpkg_geometry_columns").fetchone()[0] == "GEOMETRY"
     con.close()
+    for wk, want in (([a, a], "POLYGON"), ([b], "MULTIPOLYGON")):
+        p2 = write_geopackage(str(tmp_path / "t.gpkg"), wk, {"segment_id": list(range(1, len(wk) + 1))}, srs_epsg=32610,
+                              srs_wkt='PROJCS["WGS 84 / UTM zone 10N"]')
+        con = sqlite3.connect(p2)
+        assert con.execute("SELECT geometry_type_name FROM gpkg_geometry_columns").fetchone()[0] == want
+        assert con.execute("SELECT definition FROM gpkg_spatial_ref_sys WHERE srs_id = 32610").fetchone()[0].startswith("PROJCS")
+        con.close()
 
 
 def test_oracle_tiler_properties(oracle):
