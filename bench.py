@@ -297,8 +297,10 @@ def main():
     t0 = time.time()
     assign_ms = assign_px = assign_store_px = sweeps = assign_busy_ms = 0.0
     n_seg = 0
+    step_wall = []          # host clock after each step's calls returned (no extra synchronisation: the zonal kernels may still run)
     for _ in range(args.steps):
         lab, n_seg, st, t_seg, t_z = step()
+        step_wall.append(time.time())
         assign_ms += t_seg["assign_ms"]
         assign_busy_ms += t_seg["assign_busy_ms"]
         assign_px += t_seg["assign_px"]
@@ -448,6 +450,7 @@ def main():
             "metric": "Mpixel/s (SLIC+zonal feats) on 16384²×8-band; achieved HBM GB/s fraction",
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "step_wall_ms": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_wall[:-1], step_wall)],
             "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (NumPy RandomState on the host)" if args.host_rng else " (SURVEY 8d formula, noise drawn on the device)"),
             "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,

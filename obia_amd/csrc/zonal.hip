@@ -10,10 +10,19 @@
 namespace obia {
 
 #ifndef ZW
-#define ZW 8
+#define ZW 6
 #endif
 #ifndef ZR
 #define ZR 2
+#endif
+#ifndef ZTW
+#define ZTW 128   /* columns of a zonal_kernel tile (the moments kernel keeps Z_TILE x Z_TILE) */
+#endif
+#ifndef ZTH
+#define ZTH 64
+#endif
+#ifndef ZSLOTS
+#define ZSLOTS 64
 #endif
 constexpr int Z_TILE = 64, Z_SLOTS = 64, Z_MAXB = 16, Z_ROWS = ZR;
 
@@ -21,6 +30,15 @@ struct BandList { int n; int identity; int b[Z_MAXB]; };   // identity: b[i] == 
 // four consecutive bands of one pixel: 16 bytes at a 4-byte aligned address when the band count is not a multiple of four (the
 // author's rasters have nine) -- gfx950 loads a dwordx4 from any dword address, the type only tells the compiler so
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+typedef float z_v4f __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ld_raster_f4(const float *p) {
+    const z_v4f t = __builtin_nontemporal_load(reinterpret_cast<const z_v4f *>(p));   // the raster is read once
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+// min / max of two numbers that are known not to be NaN: ONE instruction (fminf / fmaxf first quiet both operands)
+__device__ __forceinline__ float zmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
+__device__ __forceinline__ float zmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
 
 __device__ __forceinline__ unsigned zkey(float f) {
     unsigned b = __float_as_uint(f);
@@ -31,55 +49,68 @@ __device__ __forceinline__ float zunkey(unsigned k) {
     return __uint_as_float(b);
 }
 
-// One workgroup per 64x64 tile.  A lane owns FOUR bands of ONE pixel column: lane = (column, band quad), LPP = NBP / 4
+// One workgroup per ZTW x ZTH tile.  A lane owns FOUR bands of ONE pixel column: lane = (column, band quad), LPP = NBP / 4
 // lanes per pixel, so the 64 lanes of a wave read 64 consecutive 16-byte chunks of a raster row (one 1-KB request) and a
-// workgroup of LPP waves covers the 64 columns.  Every lane walks its column down the 64 rows of the tile:
-//   per lane : runs of equal label down the column are summed in registers (sum, sum of squares in double; min, max) --
-//              24 registers of state, so the loads of the next Z_ROWS rows are in flight while the current ones are
-//              folded, and 8 waves per SIMD fit
-//   per run  : the partial goes to a 64-slot LDS hash table keyed by label (native ds_add_f64 / ds_min_u32 / ds_max_u32);
-//              a column crosses a segment boundary every ~S rows, so a lane closes ~4 runs per tile
-//   per tile : one global atomic per (tile, label, band, statistic) at the end.  A tile that holds more than 64 labels
+// workgroup of ZTW * LPP / 64 waves covers the ZTW columns.  Every lane walks its column down the rows of the tile:
+//   per lane : runs of equal label down the column are summed in registers (sum, sum of squares in double; min, max); the
+//              loads of the next Z_ROWS rows are in flight while the current ones are folded
+//   per run  : the partial goes to a ZSLOTS-slot LDS hash table keyed by label (native ds_add_f64 / ds_min_f32 / ds_max_f32)
+//   per tile : one global atomic per (tile, label, band, statistic) at the end.  A tile that holds more than ZSLOTS labels
 //              sends the overflow straight to global memory.
-template <int NBP>
-__global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_kernel(const float *__restrict__ raw, const int32_t *__restrict__ labels,
+// The walk is bound by instruction issue as much as by memory (round 3, PMC: 95 vector + 44 scalar instructions per wave and
+// row in the first version, the vector units busy half of the time at 4.5 waves per SIMD), so the row loop is kept lean:
+//   * addresses are (uniform row base) + (a lane offset that never changes): no per-row address arithmetic on the vector
+//     unit; columns / rows past the raster are clamped to the last one and their label forced to -1, so no branch guards a load
+//   * the raster is read whatever the label says (a load that waits for the label is two round trips in a row)
+//   * one test per row for "any NaN among my four values"; the clean path has no per-band conditions
+// MODE 0: the band list is 0..C-1 in order and C == NBP -- every lane reads ONE 16-byte chunk per row;
+// MODE 1: the band list is 0..C-1 in order, C not a multiple of four (the author's rasters hold nine bands): full quads are one
+//         16-byte load at dword alignment (gfx950 loads a dwordx4 from any dword address), the lanes of the last quad load their
+//         1..3 bands one by one;   MODE 2: the lanes gather their bands through the list (a subset, any order).
+template <int NBP, int MODE>
+__global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_kernel(const float *__restrict__ raw, const int32_t *__restrict__ labels,
                                                          int H, int W, int C, BandList bl, int n_labels, int start_label,
                                                          unsigned *__restrict__ g_cnt, unsigned *__restrict__ g_nan,
                                                          double *__restrict__ g_sum, double *__restrict__ g_sq,
                                                          unsigned *__restrict__ g_mn, unsigned *__restrict__ g_mx) {
-    constexpr int LPP = NBP / 4, NT = 64 * LPP;
-    __shared__ int s_key[Z_SLOTS];
-    __shared__ unsigned s_cnt[Z_SLOTS];
-    __shared__ unsigned s_nan[Z_SLOTS][NBP];
-    __shared__ double s_sum[Z_SLOTS][NBP], s_sq[Z_SLOTS][NBP];
-    __shared__ unsigned s_mn[Z_SLOTS][NBP], s_mx[Z_SLOTS][NBP];
+    constexpr int LPP = NBP / 4, NT = ZTW * LPP;
+    __shared__ int s_key[ZSLOTS];
+    __shared__ unsigned s_cnt[ZSLOTS];
+    __shared__ unsigned s_nan[ZSLOTS][NBP];
+    __shared__ double s_sum[ZSLOTS][NBP], s_sq[ZSLOTS][NBP];
+    __shared__ float s_mn[ZSLOTS][NBP], s_mx[ZSLOTS][NBP];   // (+inf, -inf) = nothing but NaNs so far
     const int tid = threadIdx.x;
     const int nb = bl.n;
-    for (int i = tid; i < Z_SLOTS; i += NT) { s_key[i] = -1; s_cnt[i] = 0; }
-    for (int i = tid; i < Z_SLOTS * NBP; i += NT) {
+    for (int i = tid; i < ZSLOTS; i += NT) { s_key[i] = -1; s_cnt[i] = 0; }
+    for (int i = tid; i < ZSLOTS * NBP; i += NT) {
         (&s_sum[0][0])[i] = 0.0; (&s_sq[0][0])[i] = 0.0; (&s_nan[0][0])[i] = 0u;
-        (&s_mn[0][0])[i] = 0xffffffffu; (&s_mx[0][0])[i] = 0u;
+        (&s_mn[0][0])[i] = INFINITY; (&s_mx[0][0])[i] = -INFINITY;
     }
     __syncthreads();
-    const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
-    const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
+    const int tiles_x = (W + ZTW - 1) / ZTW;
+    const int ty0 = (blockIdx.x / tiles_x) * ZTH, tx0 = (blockIdx.x % tiles_x) * ZTW;
     const int x = tx0 + tid / LPP, q = tid % LPP;       // column, band quad
-    const int nbq = min(4, max(0, nb - 4 * q));         // bands of this lane's quad that exist
-    const bool vec = (nb == C) && bl.identity && nbq == 4;   // all bands in order and a full quad: one 16-byte load per lane and row
+    const int nbq = min(4, max(0, nb - 4 * q));         // bands of this lane's quad that exist (>= 1: NBP is the smallest that holds nb)
     const bool col_ok = x < W;
-    int bsel[4];
+    const int xc = col_ok ? x : W - 1;                  // a column past the raster reads the last one (and is given label -1)
+    // byte offsets inside a raster row / a label row: fixed for the whole walk (a row of the raster stays below 4 GB)
+    const unsigned loff = (unsigned)xc * 4u;
+    unsigned roff[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)   // constant indices only: the band list stays in scalar registers
-        bsel[b] = (q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b];
+    for (int b = 0; b < 4; ++b) {   // constant indices only: the band list stays in scalar registers
+        const int band = MODE < 2 ? 4 * q + b : ((q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b]);
+        roff[b] = ((unsigned)xc * (unsigned)C + (unsigned)(b < nbq ? band : 0)) * 4u;
+    }
+    const bool full = MODE == 0 || (MODE == 1 && nbq == 4);
 
     int c_lab = -2, c_slot = -1;                        // one-entry cache of the last label -> slot lookup
     auto find_slot = [&](int l) -> int {
         if (l == c_lab) return c_slot;
-        const unsigned h = ((unsigned)l * 2654435761u) >> 26;
+        const unsigned h = ((unsigned)l * 2654435761u) >> 16;
         int found = -1;
 #pragma unroll 1
-        for (int probe = 0; probe < Z_SLOTS; ++probe) {
-            const int sidx = (h + probe) & (Z_SLOTS - 1);
+        for (int probe = 0; probe < ZSLOTS; ++probe) {
+            const int sidx = (h + probe) % ZSLOTS;
             const int old = atomicCAS(&s_key[sidx], -1, l);
             if (old == -1 || old == l) { found = sidx; break; }
         }
@@ -97,20 +128,21 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
         if (rl < 0) return;
         const int slot = find_slot(rl);
         if (slot >= 0) {
+            // no conditions on this path (it is executed by the whole wave whenever ONE lane closes a run): a run of NaNs only
+            // adds 0 and folds (+inf, -inf), a band slot past the last band collects zeros nobody reads
             if (q == 0) atomicAdd(&s_cnt[slot], rn);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                if (b >= nbq || !(rmn[b] <= rmx[b])) continue;   // band absent, or only NaNs in this run
                 atomicAdd(&s_sum[slot][4 * q + b], rs[b]);
                 atomicAdd(&s_sq[slot][4 * q + b], rq[b]);
-                atomicMin(&s_mn[slot][4 * q + b], zkey(rmn[b]));
-                atomicMax(&s_mx[slot][4 * q + b], zkey(rmx[b]));
+                __hip_atomic_fetch_min(&s_mn[slot][4 * q + b], rmn[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_min_f32
+                __hip_atomic_fetch_max(&s_mx[slot][4 * q + b], rmx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-        } else {   // table full (more than 64 labels in one tile): straight to global memory
+        } else {   // table full (more than ZSLOTS labels in one tile): straight to global memory
             if (q == 0) atomicAdd(&g_cnt[rl], rn);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                if (b >= nbq || !(rmn[b] <= rmx[b])) continue;
+                if (b >= nbq || !(rmn[b] <= rmx[b])) continue;   // band absent, or only NaNs in this run
                 const size_t o = (size_t)rl * nb + 4 * q + b;
                 unsafeAtomicAdd(&g_sum[o], rs[b]);
                 unsafeAtomicAdd(&g_sq[o], rq[b]);
@@ -123,42 +155,42 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
     // rows in groups of Z_ROWS: the loads of group g+1 are issued before group g is folded
     int lab[2][Z_ROWS];
     float4 val[2][Z_ROWS];
-    auto fetch = [&](int buf, int y0) {
+    // the rows are fetched in order: two uniform row pointers (scalar registers) move down the raster, a lane adds its fixed offset
+    const size_t row_bytes = (size_t)W * C * 4, lab_bytes = (size_t)W * 4;
+    const char *lrow = reinterpret_cast<const char *>(labels) + (size_t)ty0 * lab_bytes;
+    const char *rrow = reinterpret_cast<const char *>(raw) + (size_t)ty0 * row_bytes;
+    int y_next = ty0;
+    auto fetch = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < Z_ROWS; ++j) {
-            const int y = y0 + j;
-            int l = -1;
+            int l = *reinterpret_cast<const int *>(lrow + loff) - start_label;
+            if ((unsigned)l >= (unsigned)n_labels || !col_ok || y_next >= H) l = -1;
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (col_ok && y < H) {
-                const long long pix = (long long)y * W + x;
-                l = labels[pix] - start_label;
-                if (l < 0 || l >= n_labels) l = -1;
-                if (l >= 0 && nbq > 0) {
-                    const float *px = raw + pix * C;
-                    if (vec) { const f4u t = *reinterpret_cast<const f4u *>(px + 4 * q); v = make_float4(t.x, t.y, t.z, t.w); }
-                    else {
-                        v.x = px[bsel[0]];
-                        if (nbq > 1) v.y = px[bsel[1]];
-                        if (nbq > 2) v.z = px[bsel[2]];
-                        if (nbq > 3) v.w = px[bsel[3]];
-                    }
-                }
+            if (full) v = ld_raster_f4(reinterpret_cast<const float *>(rrow + roff[0]));
+            else {
+                v.x = *reinterpret_cast<const float *>(rrow + roff[0]);
+                if (nbq > 1) v.y = *reinterpret_cast<const float *>(rrow + roff[1]);
+                if (nbq > 2) v.z = *reinterpret_cast<const float *>(rrow + roff[2]);
+                if (nbq > 3) v.w = *reinterpret_cast<const float *>(rrow + roff[3]);
             }
             lab[buf][j] = l; val[buf][j] = v;
+            ++y_next;
+            if (y_next < H) { lrow += lab_bytes; rrow += row_bytes; }   // (uniform) a row past the raster reads the last one again
         }
     };
-    const int y_end = min(ty0 + Z_TILE, H);
-    fetch(0, ty0);
+    constexpr int NG = ZTH / Z_ROWS;
+    const int y_end = min(ty0 + ZTH, H);
+    fetch(0);
 #pragma unroll 1
-    for (int g = 0; g < Z_TILE / Z_ROWS; g += 2) {
+    for (int g = 0; g < NG; g += 2) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int y0 = ty0 + (g + half) * Z_ROWS;
             if (y0 >= y_end) break;                      // workgroup-uniform
-            fetch(half ^ 1, y0 + Z_ROWS);                // rows past the tile or the raster come back as label -1
+            if (g + half + 1 < NG) fetch(half ^ 1);   // rows past the raster come back as label -1
 #pragma unroll
             for (int j = 0; j < Z_ROWS; ++j) {
-                const int l = (y0 + j < y_end) ? lab[half][j] : -1;
+                const int l = lab[half][j];
                 if (l != rl) {
                     close_run();
                     rl = l; rn = 0;
@@ -168,19 +200,27 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
                 if (l < 0) continue;
                 rn += 1;
                 const float v[4] = {val[half][j].x, val[half][j].y, val[half][j].z, val[half][j].w};
+                if ((v[0] == v[0]) & (v[1] == v[1]) & (v[2] == v[2]) & (v[3] == v[3])) {   // (a band slot past the last band holds 0)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b >= nbq) continue;
-                    if (v[b] == v[b]) {
+                    for (int b = 0; b < 4; ++b) {
                         const double dv = (double)v[b];
-                        rs[b] += dv; rq[b] += dv * dv;
-                        rmn[b] = fminf(rmn[b], v[b]); rmx[b] = fmaxf(rmx[b], v[b]);
-                    } else {
-                        // NaN pixels are dropped per band (`band[~isnan]`, segment_statistics.py:145-147): remember how
-                        // many, the per-band count is (label count - NaN count).  Rare: direct atomics.
-                        const int slot = find_slot(l);
-                        if (slot >= 0) atomicAdd(&s_nan[slot][4 * q + b], 1u);
-                        else atomicAdd(&g_nan[(size_t)l * nb + 4 * q + b], 1u);
+                        rs[b] += dv; rq[b] = fma(dv, dv, rq[b]);
+                        rmn[b] = zmin(rmn[b], v[b]); rmx[b] = zmax(rmx[b], v[b]);
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (v[b] == v[b]) {
+                            const double dv = (double)v[b];
+                            rs[b] += dv; rq[b] = fma(dv, dv, rq[b]);
+                            rmn[b] = zmin(rmn[b], v[b]); rmx[b] = zmax(rmx[b], v[b]);
+                        } else {
+                            // NaN pixels are dropped per band (`band[~isnan]`, segment_statistics.py:145-147): remember how
+                            // many, the per-band count is (label count - NaN count).  Rare: direct atomics.
+                            const int slot = find_slot(l);
+                            if (slot >= 0) atomicAdd(&s_nan[slot][4 * q + b], 1u);
+                            else if (b < nbq) atomicAdd(&g_nan[(size_t)l * nb + 4 * q + b], 1u);
+                        }
                     }
                 }
             }
@@ -188,17 +228,17 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
     }
     close_run();
     __syncthreads();
-    for (int i = tid; i < Z_SLOTS * nb; i += NT) {
+    for (int i = tid; i < ZSLOTS * nb; i += NT) {
         const int slot = i / nb, b = i - slot * nb;
         const int l = s_key[slot];
         if (l < 0) continue;
         if (b == 0 && s_cnt[slot]) atomicAdd(&g_cnt[l], s_cnt[slot]);
         if (s_nan[slot][b]) atomicAdd(&g_nan[(size_t)l * nb + b], s_nan[slot][b]);
-        if (s_mn[slot][b] == 0xffffffffu && s_mx[slot][b] == 0u) continue;   // only NaNs (or nothing) for this band
+        if (!(s_mn[slot][b] <= s_mx[slot][b])) continue;   // only NaNs (or nothing) for this band
         unsafeAtomicAdd(&g_sum[(size_t)l * nb + b], s_sum[slot][b]);
         unsafeAtomicAdd(&g_sq[(size_t)l * nb + b], s_sq[slot][b]);
-        atomicMin(&g_mn[(size_t)l * nb + b], s_mn[slot][b]);
-        atomicMax(&g_mx[(size_t)l * nb + b], s_mx[slot][b]);
+        atomicMin(&g_mn[(size_t)l * nb + b], zkey(s_mn[slot][b]));
+        atomicMax(&g_mx[(size_t)l * nb + b], zkey(s_mx[slot][b]));
     }
 }
 
@@ -461,6 +501,7 @@ int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int 
     for (int i = bl.n; i < Z_MAXB; ++i) bl.b[i] = 0;
     bl.identity = 1;
     for (int i = 0; i < bl.n; ++i) if (bl.b[i] != i) bl.identity = 0;
+    if ((long long)W * C * 4 >= (1ll << 32)) { set_error("a raster row of %lld bytes is not supported (4 GB at most)", (long long)W * C * 4); return OBIA_E_UNSUPPORTED; }
     if (n_labels == 0) return OBIA_OK;
     Arena &A = ctx->arena;
     const size_t nl = (size_t)n_labels, nlb = nl * bl.n;
@@ -471,15 +512,23 @@ int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int 
     int ib = cdiv((long long)nlb, 256);
     if (ib > 4096) ib = 4096;
     hipLaunchKernelGGL(zonal_init_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx, (long long)n_labels, bl.n);
-    const int tiles = cdiv(W, Z_TILE) * cdiv(H, Z_TILE);
-#define LAUNCH_ZONAL(NBPV)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_kernel<NBPV>), dim3(tiles), dim3(16 * NBPV), 0, ctx->stream, raw, labels, H, W, C, \
+    const int tiles = cdiv(W, ZTW) * cdiv(H, ZTH);
+    const bool ident = bl.identity && bl.n == C;
+#define LAUNCH_ZONAL_MODE(NBPV, MODEV)                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_kernel<NBPV, MODEV>), dim3(tiles), dim3(ZTW / 4 * NBPV), 0, ctx->stream, raw, labels, H, W, C, \
                        bl, n_labels, start_label, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx)
+#define LAUNCH_ZONAL(NBPV)                                                                                          \
+    do {                                                                                                            \
+        if (ident && bl.n == NBPV) LAUNCH_ZONAL_MODE(NBPV, 0);                                                      \
+        else if (ident) LAUNCH_ZONAL_MODE(NBPV, 1);                                                                 \
+        else LAUNCH_ZONAL_MODE(NBPV, 2);                                                                            \
+    } while (0)
     if (bl.n <= 4) LAUNCH_ZONAL(4);
     else if (bl.n <= 8) LAUNCH_ZONAL(8);
     else if (bl.n <= 12) LAUNCH_ZONAL(12);   // (nine bands -- the author's rasters -- ran as sixteen until round 3: a quarter of the lanes idle)
     else LAUNCH_ZONAL(16);
 #undef LAUNCH_ZONAL
+#undef LAUNCH_ZONAL_MODE
     hipLaunchKernelGGL(zonal_finalize_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx,
                        (long long)n_labels, bl.n, count, mean, var, mn, mx);
     OBIA_HIP_TRY(hipGetLastError());

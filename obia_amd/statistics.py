@@ -54,11 +54,12 @@ def zonal_stats(raw, labels, bands=None, start_label=1, n_labels=None, ctx=None,
         B = len(bl)
         barr = np.ascontiguousarray(bl, np.int32)
         dev = r.device
-        cnt = torch.zeros((n_labels,), dtype=torch.int64, device=dev)
-        mean = torch.full((n_labels, B), float("nan"), dtype=torch.float64, device=dev)
-        var = torch.full_like(mean, float("nan"))
-        mn = torch.full((n_labels, B), float("nan"), dtype=torch.float32, device=dev)
-        mx = torch.full_like(mn, float("nan"))
+        # (zonal_finalize_kernel writes every entry -- NaN for an empty label -- so the outputs need no fill)
+        cnt = torch.empty((n_labels,), dtype=torch.int64, device=dev)
+        mean = torch.empty((n_labels, B), dtype=torch.float64, device=dev)
+        var = torch.empty_like(mean)
+        mn = torch.empty((n_labels, B), dtype=torch.float32, device=dev)
+        mx = torch.empty_like(mn)
         c = ctx or _lib.default_context(dev.index or 0)
         torch.cuda.current_stream(dev.index or 0).synchronize()
         _lib.check(lib.obia_zonal_stats_f32_dev(c.handle, r.data_ptr(), lab.data_ptr(), H, W, C, _lib.np_ptr(barr), B,
