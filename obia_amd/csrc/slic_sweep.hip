@@ -188,6 +188,106 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
 }
 
+// The same step with ONE LANE per centroid (round 3).  The grouped kernel above spends 16 lanes on a centroid: 22 000 waves per
+// launch of a bench batch, each alive for 3.5 us, on a chip that is a quarter full for the 17-20 us the launch lasts (PMC: 2 200
+// resident waves on average) -- the launch is bound by wave dispatch, and there are 180 such launches per step of the tiler.  Here a
+// lane reads its centroid's accumulator record (16-byte loads, all in flight together), clears it, and writes the centroid record:
+// sixteen times fewer waves, and one dependent round trip less (the problem comes with the block index, not through cent_prob[k]).
+// Same arithmetic, operation for operation.
+template <int CP>
+__global__ __launch_bounds__(64) void slic_prep_lane_kernel(const SlicProblem *__restrict__ probs, int p_base,
+                                                             int first, int slic_zero, const float *__restrict__ seed,
+                                                             unsigned long long *__restrict__ acc, int RQ, double inv_fscale,
+                                                             float *__restrict__ cent, int *__restrict__ head,
+                                                             int *__restrict__ head_other,
+                                                             int total_cells, int *__restrict__ bin_stamp, int sweep_id,
+                                                             int cell_base) {
+    constexpr int RS = CENT_REC + CP;
+    constexpr int NQ = (CP + 3 + 1) / 2;   // 16-byte pairs of the accumulator record that are in use: colours | n | sum_y | sum_x
+    {   // the bins of the NEXT sweep (see slic_prep_kernel)
+        const int nthr = gridDim.x * gridDim.y * blockDim.x;
+        for (int i = cell_base + (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < total_cells; i += nthr) head_other[i] = -1;
+    }
+    // grid = (blocks of 64 centroids, problems of the group): the problem descriptor is workgroup-uniform (scalar loads that depend
+    // on nothing), so the chain of dependent round trips is descriptor -> records -> bin head
+    const SlicProblem P = probs[p_base + blockIdx.y];
+    const int kl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kl >= P.K) return;
+    const int k = P.cent_off + kl;
+    float4 *hrec = reinterpret_cast<float4 *>(cent + (size_t)k * RS);   // records are 16-byte aligned (RS is a multiple of 4)
+    ulonglong2 *a2 = reinterpret_cast<ulonglong2 *>(acc + (size_t)k * RQ);
+    const float4 h0 = hrec[0], h1 = hrec[1];
+    float4 oc[CP / 4];
+    ulonglong2 aq[NQ];
+    if (!first) {
+#pragma unroll
+        for (int i = 0; i < CP / 4; ++i) oc[i] = hrec[2 + i];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) aq[i] = a2[i];
+    }
+    const float old_cy = h0.x, old_cx = h0.y;
+    float cy, cx;
+    bool moved;
+    if (first) {
+        cy = seed[2 * (size_t)k];
+        cx = seed[2 * (size_t)k + 1];
+#pragma unroll
+        for (int i = 0; i < CP / 4; ++i) hrec[2 + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // initial centroid colour is zero (slic_superpixels.py:298-300)
+        moved = true;
+    } else {
+        unsigned long long q[2 * NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { q[2 * i] = aq[i].x; q[2 * i + 1] = aq[i].y; a2[i] = make_ulonglong2(0ull, 0ull); }
+        // n, sum_y and sum_x are full 64-bit words (sum_y reaches 2^32 as soon as (pixels of a cluster) x (row) does)
+        // uint64 -> float by way of double (exact below 2^53, which a count or a coordinate sum never reaches, so the one rounding is
+        // the same): the direct conversion expands to a 64-bit shift by a register, and when that register is the last one the kernel
+        // allocates the MI355X reads a wrong shift amount (tools/check_shift64.py -- the build fails on such an instruction)
+        const float fn = (float)(double)q[CP];
+        // segments[k, c] /= n  in float32; n == 0 -> 0/0 = NaN centroid, as in the reference
+        cy = (float)(double)q[CP + 1] / fn;
+        cx = (float)(double)q[CP + 2] / fn;
+        moved = false;
+        float nc[CP];
+#pragma unroll
+        for (int ch = 0; ch < CP; ++ch) {
+            const float sum = (float)((double)(long long)q[ch] * inv_fscale);
+            nc[ch] = sum / fn;
+        }
+#pragma unroll
+        for (int i = 0; i < CP / 4; ++i) {
+            moved |= __float_as_uint(nc[4 * i]) != __float_as_uint(oc[i].x) || __float_as_uint(nc[4 * i + 1]) != __float_as_uint(oc[i].y)
+                  || __float_as_uint(nc[4 * i + 2]) != __float_as_uint(oc[i].z) || __float_as_uint(nc[4 * i + 3]) != __float_as_uint(oc[i].w);
+            hrec[2 + i] = make_float4(nc[4 * i], nc[4 * i + 1], nc[4 * i + 2], nc[4 * i + 3]);
+        }
+        moved |= __float_as_uint(cy) != __float_as_uint(old_cy) || __float_as_uint(cx) != __float_as_uint(old_cx);
+    }
+    // SLIC-zero: slot 7 of the record carries max_dist_color[k] from sweep to sweep (see slic_prep_kernel)
+    const float mdc = slic_zero ? ((first || slic_zero == 2) ? 1.0f : h1.w) : 0.0f;
+    if (bin_stamp && moved && !first && old_cy == old_cy && old_cx == old_cx) {   // the bin it leaves
+        int oby = (int)(old_cy / (float)P.sy), obx = (int)(old_cx / (float)P.sx);
+        oby = oby < 0 ? 0 : (oby >= P.ncy ? P.ncy - 1 : oby);
+        obx = obx < 0 ? 0 : (obx >= P.ncx ? P.ncx - 1 : obx);
+        bin_stamp[P.cell_off + oby * P.ncx + obx] = sweep_id;
+    }
+    if (!(cy == cy) || !(cx == cx)) {   // NaN centroid: its window is empty, it is never binned
+        hrec[0] = make_float4(cy, cx, 0.0f, 0.0f);
+        hrec[1] = make_float4(0.0f, 0.0f, __int_as_float(-1), mdc);
+        return;
+    }
+    // z/y/x window of _slic_cython: (ssize_t)max(c - 2*step, 0) .. (ssize_t)min(c + 2*step + 1, size)
+    float fy0 = cy - (float)(2 * P.sy); fy0 = (0.0f > fy0) ? 0.0f : fy0;
+    float fy1 = (cy + (float)(2 * P.sy)) + 1.0f; fy1 = ((float)P.H < fy1) ? (float)P.H : fy1;
+    float fx0 = cx - (float)(2 * P.sx); fx0 = (0.0f > fx0) ? 0.0f : fx0;
+    float fx1 = (cx + (float)(2 * P.sx)) + 1.0f; fx1 = ((float)P.W < fx1) ? (float)P.W : fx1;
+    int by = (int)(cy / (float)P.sy), bx = (int)(cx / (float)P.sx);
+    by = by < 0 ? 0 : (by >= P.ncy ? P.ncy - 1 : by);
+    bx = bx < 0 ? 0 : (bx >= P.ncx ? P.ncx - 1 : bx);
+    const int link = atomicExch(&head[P.cell_off + by * P.ncx + bx], k);
+    hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
+    hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(link), mdc);
+    if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
+}
+
 // float feature -> 32-bit fixed point.  fs is a power of two chosen in slic_features_finish so that |f * fs| < 2^29:
 // the product is exact, the conversion truncates only what lies below 2^-29 of the largest feature (floats above
 // 1/64 of it are integers after the scaling), four of them add up in an int32 and every total stays below 2^62.
@@ -1053,7 +1153,7 @@ __global__ __launch_bounds__(256) void slic_maxdist_kernel(const SlicProblem *__
 
 // A group of consecutive problems of the batch whose prep / sweep chain runs on its own stream (slic_run_sweeps): the
 // centroids [k0, k1), bins [cell0, cell1) and tiles [tile0, tile1) of the batch's tables.
-struct SweepGroup { int k0, k1, cell0, cell1, tile0, tile1; long long pix0, pix1; hipStream_t stream; };
+struct SweepGroup { int k0, k1, cell0, cell1, tile0, tile1; long long pix0, pix1; hipStream_t stream; int p0, p1, kmax; };   // [p0, p1): the group's problems, kmax: their largest K
 
 struct FixedPointState {   // exit_on_fixed_point bookkeeping (device pointers; null when the option is off)
     int *bin_stamp = nullptr, *tile_lp = nullptr, *cache_k = nullptr;
@@ -1201,6 +1301,8 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
             sg.tile0 = P0.tile_off; sg.tile1 = last ? (int)b.total_tiles_all : b.probs[cut[g + 1]].tile_off;
             sg.pix0 = P0.pix_off;   sg.pix1 = last ? b.total_pix : b.probs[cut[g + 1]].pix_off;
             sg.stream = g == 0 ? ctx->stream : ctx->side[g - 1];
+            sg.p0 = cut[g]; sg.p1 = cut[g + 1]; sg.kmax = 1;
+            for (int p = sg.p0; p < sg.p1; ++p) if (b.probs[p].K > sg.kmax) sg.kmax = b.probs[p].K;
             groups.push_back(sg);
         }
     }
@@ -1244,7 +1346,19 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 // SLIC-zero: the per-cluster colour scale restarts at 1 with the colour pass and is carried afterwards
                 const int zmode = (b.slic_zero && !ignore_color) ? (it == 0 ? 2 : 1) : 0;
                 const long long nk = sg.k1 > sg.k0 ? sg.k1 - sg.k0 : 1;   // (at least one block: it also resets the group's bins)
-                if (RQ == 16)
+                const bool prep_grouped = std::getenv("OBIA_PREP_GROUPED") != nullptr;   // developer switch (A/B timing, tests/test_gpu_prep_kernels.py): the 16-lanes-per-centroid kernel
+#define LAUNCH_PREP_LANE(CPV)                                                                                         \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_lane_kernel<CPV>), dim3(cdiv(sg.kmax, 64), sg.p1 > sg.p0 ? sg.p1 - sg.p0 : 1), dim3(64), 0, \
+                       sg.stream, b.d_probs, sg.p1 > sg.p0 ? sg.p0 : 0, first ? 1 : 0, zmode, b.d_seed, b.d_acc, RQ, 1.0 / b.fscale, b.d_cent,  \
+                       head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.cell0)
+                if (!prep_grouped) {
+                    switch (b.CP) {
+                        case 4: LAUNCH_PREP_LANE(4); break;
+                        case 8: LAUNCH_PREP_LANE(8); break;
+                        case 12: LAUNCH_PREP_LANE(12); break;
+                        default: LAUNCH_PREP_LANE(16); break;
+                    }
+                } else if (RQ == 16)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv(nk * 16, 256)), dim3(256), 0,
                                        sg.stream, b.d_probs, b.d_cent_prob, sg.k1, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
                                        1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0);
@@ -1252,6 +1366,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv(nk * 32, 256)), dim3(256), 0,
                                        sg.stream, b.d_probs, b.d_cent_prob, sg.k1, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
                                        1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0);
+#undef LAUNCH_PREP_LANE
                 b.d_head_cur = head_cur;
                 debug_sync(ctx, "sweeps: prep");
                 first = false;
