@@ -32,9 +32,16 @@ struct BandList { int n; int identity; int b[Z_MAXB]; };   // identity: b[i] == 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 
 typedef float z_v4f __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ float4 ld_raster_f4(const float *p) {
-    const z_v4f t = __builtin_nontemporal_load(reinterpret_cast<const z_v4f *>(p));   // the raster is read once
-    return make_float4(t.x, t.y, t.z, t.w);
+typedef float z_v3f __attribute__((ext_vector_type(3), aligned(4)));
+// the BPL consecutive bands of a lane: ONE nontemporal load (the raster is read once) of 16 or 12 bytes at dword alignment
+template <int BPL> __device__ __forceinline__ void ld_raster(const float *p, float *v);
+template <> __device__ __forceinline__ void ld_raster<4>(const float *p, float *v) {
+    const z_v4f t = __builtin_nontemporal_load(reinterpret_cast<const z_v4f *>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld_raster<3>(const float *p, float *v) {
+    const z_v3f t = __builtin_nontemporal_load(reinterpret_cast<const z_v3f *>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z;
 }
 // min / max of two numbers that are known not to be NaN: ONE instruction (fminf / fmaxf first quiet both operands)
 __device__ __forceinline__ float zmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
@@ -67,13 +74,13 @@ __device__ __forceinline__ float zunkey(unsigned k) {
 // MODE 1: the band list is 0..C-1 in order, C not a multiple of four (the author's rasters hold nine bands): full quads are one
 //         16-byte load at dword alignment (gfx950 loads a dwordx4 from any dword address), the lanes of the last quad load their
 //         1..3 bands one by one;   MODE 2: the lanes gather their bands through the list (a subset, any order).
-template <int NBP, int MODE>
-__global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_kernel(const float *__restrict__ raw, const int32_t *__restrict__ labels,
+template <int LPP, int BPL, int MODE>
+__global__ __launch_bounds__(ZTW * LPP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_kernel(const float *__restrict__ raw, const int32_t *__restrict__ labels,
                                                          int H, int W, int C, BandList bl, int n_labels, int start_label,
                                                          unsigned *__restrict__ g_cnt, unsigned *__restrict__ g_nan,
                                                          double *__restrict__ g_sum, double *__restrict__ g_sq,
                                                          unsigned *__restrict__ g_mn, unsigned *__restrict__ g_mx) {
-    constexpr int LPP = NBP / 4, NT = ZTW * LPP;
+    constexpr int NBP = LPP * BPL, NT = ZTW * LPP;   // band slots of a pixel, lanes of the workgroup
     __shared__ int s_key[ZSLOTS];
     __shared__ unsigned s_cnt[ZSLOTS];
     __shared__ unsigned s_nan[ZSLOTS][NBP];
@@ -89,19 +96,19 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
     __syncthreads();
     const int tiles_x = (W + ZTW - 1) / ZTW;
     const int ty0 = (blockIdx.x / tiles_x) * ZTH, tx0 = (blockIdx.x % tiles_x) * ZTW;
-    const int x = tx0 + tid / LPP, q = tid % LPP;       // column, band quad
-    const int nbq = min(4, max(0, nb - 4 * q));         // bands of this lane's quad that exist (>= 1: NBP is the smallest that holds nb)
+    const int x = tx0 + tid / LPP, q = tid % LPP;       // column, band group (BPL bands: a quad, or a triple for 3 / 6 / 9 bands)
+    const int nbq = min(BPL, max(0, nb - BPL * q));     // bands of this lane's group that exist (>= 1: NBP is the smallest that holds nb)
     const bool col_ok = x < W;
     const int xc = col_ok ? x : W - 1;                  // a column past the raster reads the last one (and is given label -1)
     // byte offsets inside a raster row / a label row: fixed for the whole walk (a row of the raster stays below 4 GB)
     const unsigned loff = (unsigned)xc * 4u;
-    unsigned roff[4];
+    unsigned roff[BPL];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {   // constant indices only: the band list stays in scalar registers
-        const int band = MODE < 2 ? 4 * q + b : ((q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b]);
+    for (int b = 0; b < BPL; ++b) {   // constant indices only: the band list stays in scalar registers
+        const int band = MODE < 2 ? BPL * q + b : ((q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b]);   // (MODE 2 comes with BPL == 4)
         roff[b] = ((unsigned)xc * (unsigned)C + (unsigned)(b < nbq ? band : 0)) * 4u;
     }
-    const bool full = MODE == 0 || (MODE == 1 && nbq == 4);
+    const bool full = MODE == 0 || (MODE == 1 && nbq == BPL);
 
     int c_lab = -2, c_slot = -1;                        // one-entry cache of the last label -> slot lookup
     auto find_slot = [&](int l) -> int {
@@ -120,10 +127,10 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
 
     int rl = -1;
     unsigned rn = 0;
-    double rs[4], rq[4];
-    float rmn[4], rmx[4];
+    double rs[BPL], rq[BPL];
+    float rmn[BPL], rmx[BPL];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
+    for (int b = 0; b < BPL; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
     auto close_run = [&]() {
         if (rl < 0) return;
         const int slot = find_slot(rl);
@@ -132,18 +139,18 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
             // adds 0 and folds (+inf, -inf), a band slot past the last band collects zeros nobody reads
             if (q == 0) atomicAdd(&s_cnt[slot], rn);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                atomicAdd(&s_sum[slot][4 * q + b], rs[b]);
-                atomicAdd(&s_sq[slot][4 * q + b], rq[b]);
-                __hip_atomic_fetch_min(&s_mn[slot][4 * q + b], rmn[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_min_f32
-                __hip_atomic_fetch_max(&s_mx[slot][4 * q + b], rmx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int b = 0; b < BPL; ++b) {
+                atomicAdd(&s_sum[slot][BPL * q + b], rs[b]);
+                atomicAdd(&s_sq[slot][BPL * q + b], rq[b]);
+                __hip_atomic_fetch_min(&s_mn[slot][BPL * q + b], rmn[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_min_f32
+                __hip_atomic_fetch_max(&s_mx[slot][BPL * q + b], rmx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {   // table full (more than ZSLOTS labels in one tile): straight to global memory
             if (q == 0) atomicAdd(&g_cnt[rl], rn);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < BPL; ++b) {
                 if (b >= nbq || !(rmn[b] <= rmx[b])) continue;   // band absent, or only NaNs in this run
-                const size_t o = (size_t)rl * nb + 4 * q + b;
+                const size_t o = (size_t)rl * nb + BPL * q + b;
                 unsafeAtomicAdd(&g_sum[o], rs[b]);
                 unsafeAtomicAdd(&g_sq[o], rq[b]);
                 atomicMin(&g_mn[o], zkey(rmn[b]));
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
 
     // rows in groups of Z_ROWS: the loads of group g+1 are issued before group g is folded
     int lab[2][Z_ROWS];
-    float4 val[2][Z_ROWS];
+    float val[2][Z_ROWS][BPL];
     // the rows are fetched in order: two uniform row pointers (scalar registers) move down the raster, a lane adds its fixed offset
     const size_t row_bytes = (size_t)W * C * 4, lab_bytes = (size_t)W * 4;
     const char *lrow = reinterpret_cast<const char *>(labels) + (size_t)ty0 * lab_bytes;
@@ -165,15 +172,17 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
         for (int j = 0; j < Z_ROWS; ++j) {
             int l = *reinterpret_cast<const int *>(lrow + loff) - start_label;
             if ((unsigned)l >= (unsigned)n_labels || !col_ok || y_next >= H) l = -1;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (full) v = ld_raster_f4(reinterpret_cast<const float *>(rrow + roff[0]));
+            float v[BPL];
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) v[b] = 0.0f;
+            if (full) ld_raster<BPL>(reinterpret_cast<const float *>(rrow + roff[0]), v);
             else {
-                v.x = *reinterpret_cast<const float *>(rrow + roff[0]);
-                if (nbq > 1) v.y = *reinterpret_cast<const float *>(rrow + roff[1]);
-                if (nbq > 2) v.z = *reinterpret_cast<const float *>(rrow + roff[2]);
-                if (nbq > 3) v.w = *reinterpret_cast<const float *>(rrow + roff[3]);
+#pragma unroll
+                for (int b = 0; b < BPL; ++b) if (b < nbq) v[b] = *reinterpret_cast<const float *>(rrow + roff[b]);
             }
-            lab[buf][j] = l; val[buf][j] = v;
+            lab[buf][j] = l;
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) val[buf][j][b] = v[b];
             ++y_next;
             if (y_next < H) { lrow += lab_bytes; rrow += row_bytes; }   // (uniform) a row past the raster reads the last one again
         }
@@ -195,21 +204,24 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
                     close_run();
                     rl = l; rn = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
+                    for (int b = 0; b < BPL; ++b) { rs[b] = 0.0; rq[b] = 0.0; rmn[b] = INFINITY; rmx[b] = -INFINITY; }
                 }
                 if (l < 0) continue;
                 rn += 1;
-                const float v[4] = {val[half][j].x, val[half][j].y, val[half][j].z, val[half][j].w};
-                if ((v[0] == v[0]) & (v[1] == v[1]) & (v[2] == v[2]) & (v[3] == v[3])) {   // (a band slot past the last band holds 0)
+                const float *v = val[half][j];
+                bool clean = true;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < BPL; ++b) clean &= (v[b] == v[b]);
+                if (clean) {   // (a band slot past the last band holds 0)
+#pragma unroll
+                    for (int b = 0; b < BPL; ++b) {
                         const double dv = (double)v[b];
                         rs[b] += dv; rq[b] = fma(dv, dv, rq[b]);
                         rmn[b] = zmin(rmn[b], v[b]); rmx[b] = zmax(rmx[b], v[b]);
                     }
                 } else {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
+                    for (int b = 0; b < BPL; ++b) {
                         if (v[b] == v[b]) {
                             const double dv = (double)v[b];
                             rs[b] += dv; rq[b] = fma(dv, dv, rq[b]);
@@ -218,8 +230,8 @@ __global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(Z
                             // NaN pixels are dropped per band (`band[~isnan]`, segment_statistics.py:145-147): remember how
                             // many, the per-band count is (label count - NaN count).  Rare: direct atomics.
                             const int slot = find_slot(l);
-                            if (slot >= 0) atomicAdd(&s_nan[slot][4 * q + b], 1u);
-                            else if (b < nbq) atomicAdd(&g_nan[(size_t)l * nb + 4 * q + b], 1u);
+                            if (slot >= 0) atomicAdd(&s_nan[slot][BPL * q + b], 1u);
+                            else if (b < nbq) atomicAdd(&g_nan[(size_t)l * nb + BPL * q + b], 1u);
                         }
                     }
                 }
@@ -514,19 +526,24 @@ int zonal_stats_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, int 
     hipLaunchKernelGGL(zonal_init_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx, (long long)n_labels, bl.n);
     const int tiles = cdiv(W, ZTW) * cdiv(H, ZTH);
     const bool ident = bl.identity && bl.n == C;
-#define LAUNCH_ZONAL_MODE(NBPV, MODEV)                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_kernel<NBPV, MODEV>), dim3(tiles), dim3(ZTW / 4 * NBPV), 0, ctx->stream, raw, labels, H, W, C, \
+#define LAUNCH_ZONAL_MODE(LPPV, BPLV, MODEV)                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_kernel<LPPV, BPLV, MODEV>), dim3(tiles), dim3(ZTW * LPPV), 0, ctx->stream, raw, labels, H, W, C, \
                        bl, n_labels, start_label, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx)
-#define LAUNCH_ZONAL(NBPV)                                                                                          \
+#define LAUNCH_ZONAL(LPPV)                                                                                          \
     do {                                                                                                            \
-        if (ident && bl.n == NBPV) LAUNCH_ZONAL_MODE(NBPV, 0);                                                      \
-        else if (ident) LAUNCH_ZONAL_MODE(NBPV, 1);                                                                 \
-        else LAUNCH_ZONAL_MODE(NBPV, 2);                                                                            \
+        if (ident && bl.n == 4 * LPPV) LAUNCH_ZONAL_MODE(LPPV, 4, 0);                                               \
+        else if (ident) LAUNCH_ZONAL_MODE(LPPV, 4, 1);                                                              \
+        else LAUNCH_ZONAL_MODE(LPPV, 4, 2);                                                                         \
     } while (0)
-    if (bl.n <= 4) LAUNCH_ZONAL(4);
-    else if (bl.n <= 8) LAUNCH_ZONAL(8);
-    else if (bl.n <= 12) LAUNCH_ZONAL(12);   // (nine bands -- the author's rasters -- ran as sixteen until round 3: a quarter of the lanes idle)
-    else LAUNCH_ZONAL(16);
+    // 3 / 6 / 9 bands in order (an RGB raster; the author's nine bands): lanes own band TRIPLES -- one 12-byte load per lane and row,
+    // no padded band slots, a quarter fewer lanes' worth of arithmetic per pixel than quads with a partial last one
+    if (ident && bl.n == 3) LAUNCH_ZONAL_MODE(1, 3, 0);
+    else if (ident && bl.n == 6) LAUNCH_ZONAL_MODE(2, 3, 0);
+    else if (ident && bl.n == 9) LAUNCH_ZONAL_MODE(3, 3, 0);
+    else if (bl.n <= 4) LAUNCH_ZONAL(1);
+    else if (bl.n <= 8) LAUNCH_ZONAL(2);
+    else if (bl.n <= 12) LAUNCH_ZONAL(3);
+    else LAUNCH_ZONAL(4);
 #undef LAUNCH_ZONAL
 #undef LAUNCH_ZONAL_MODE
     hipLaunchKernelGGL(zonal_finalize_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_cnt, g_bcnt, g_sum, g_sq, g_mn, g_mx,
