@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OBIA_ABI_VERSION 1
+#define OBIA_ABI_VERSION 2   /* 2 (round 3): obia_slic_params grew sigma_zyx */
 
 #define OBIA_OK 0
 #define OBIA_E_INVALID (-1)     /* bad argument (Python side raises ValueError)                     */
@@ -73,6 +73,13 @@ typedef struct obia_slic_params {
                                       the result is bit-identical to running all max_num_iter sweeps (the
                                       reference's own `if change == 0: break` intends this but never fires).
                                       0: always run max_num_iter sweeps.  Default 0.                    */
+    int32_t reserved;              /* (keeps the doubles below 8-byte aligned; 0)                          */
+    double sigma_zyx[3];           /* scikit-image `sigma`: Gaussian pre-smoothing per axis (depth, row, column) of the
+                                      (1, H, W, C) image slic() builds -- scipy.ndimage.gaussian_filter, mode 'reflect',
+                                      truncate 4, applied after the Lab conversion and before `* 1/compactness`
+                                      (slic_superpixels.py; a scalar `sigma` is the same value three times: the one-plane
+                                      depth axis is filtered too).  0 = none, the default.  `spacing` is not supported
+                                      (2-D rasters: it only matters for volumes).                                      */
 } obia_slic_params;
 
 void obia_slic_default_params(obia_slic_params *p);

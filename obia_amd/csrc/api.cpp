@@ -24,6 +24,8 @@ int check_slic_args(const float *img, int H, int W, int C, const obia_slic_param
     if (!(p->compactness > 0.0)) { set_error("compactness must be positive"); return OBIA_E_INVALID; }
     if (p->n_segments <= 0) { set_error("n_segments must be positive"); return OBIA_E_INVALID; }
     if (p->max_num_iter < 0) { set_error("max_num_iter must be >= 0"); return OBIA_E_INVALID; }
+    for (int i = 0; i < 3; ++i)
+        if (!(p->sigma_zyx[i] >= 0.0)) { set_error("sigma must be >= 0"); return OBIA_E_INVALID; }
     return OBIA_OK;
 }
 
@@ -39,6 +41,7 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.max_iter = p->max_num_iter;
     b.exit_on_fixed_point = p->exit_on_fixed_point != 0;
     b.slic_zero = p->slic_zero != 0;
+    for (int i = 0; i < 3; ++i) b.sigma[i] = p->sigma_zyx[i];
     b.total_pix = (long long)H * W;
     SlicProblem P{};
     P.H = H; P.W = W; P.pix_off = 0; P.feat_off = 0; P.XB = feat_xb(W); P.fb_off = 0;

@@ -313,6 +313,8 @@ void obia_slic_default_params(obia_slic_params *p) {
     p->start_label = 1;
     p->normalize_bands = 0;
     p->exit_on_fixed_point = 0;
+    p->reserved = 0;
+    p->sigma_zyx[0] = p->sigma_zyx[1] = p->sigma_zyx[2] = 0.0;
 }
 
 int obia_set_profiling(obia_ctx *ctx, int enabled) {

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void features_planes_kernel(const float *__res
                                                               const SrcWindow *__restrict__ wins,
                                                               const unsigned *__restrict__ keys, int normalize,
                                                               int to_lab, float ratio, float *__restrict__ feat,
-                                                              unsigned *__restrict__ maxabs_bits, float *__restrict__ fbox) {
+                                                              unsigned *__restrict__ maxabs_bits, float *__restrict__ fbox, int dense) {
+    // dense: `src` is not the caller's raster but the per-window [h][w][CP] arrays of the smoothing passes (features_kernel's layout)
     const int p = blockIdx.y;
     const SrcWindow wdw = wins[p];
     float bmn[CP], bden[CP];
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(256) void features_planes_kernel(const float *__res
         for (int i = 0; i < 4; ++i) {
             const int y = 4 * q + i;
             if (y < wdw.h && x < wdw.w) {
-                const float *px = src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
+                const float *px = dense ? src + (wdw.pix_off + (long long)y * wdw.w + x) * CP
+                                        : src + ((long long)(wdw.y0 + y) * Ws + wdw.x0 + x) * C;
                 local_max = fmaxf(local_max, feature_pixel<CP>(px, C, vec, normalize, to_lab, ratio, bmn, bden, v[i]));
             } else {
 #pragma unroll
@@ -365,10 +367,89 @@ __global__ void keys_init_kernel(unsigned *keys, int nkeys, int ntot) {
     if (i < ntot) keys[i] = (i < nkeys && (i & 1) == 0) ? 0xffffffffu : 0u;
 }
 
+
+// ---- Gaussian pre-smoothing (slic(..., sigma=...)) ---------------------------------------------------------------------------
+// One axis pass of scipy.ndimage.correlate1d with symmetric weights and mode 'reflect' (d c b a | a b c d | d c b a, repeated), as
+// gaussian_filter applies it per axis: the line is read as double,  tmp = line[i] * w[0];  for j = r .. 1:
+// tmp += (line[i - j] + line[i + j]) * w[j]  (outermost pair first), the result stored in float32.  Per-window dense arrays
+// [h][w][CP]; AXIS 0 is the depth axis of the (1, H, W, C) image slic() builds: one plane, every tap reads the pixel itself.
+template <int AXIS>
+__global__ __launch_bounds__(256) void gauss_axis_kernel(const SrcWindow *__restrict__ wins, const float *__restrict__ in,
+                                                         float *__restrict__ out, int CP, const double *__restrict__ w, int r) {
+    const SrcWindow wdw = wins[blockIdx.y];
+    const long long n_el = (long long)wdw.h * wdw.w * CP;
+    const float *a = in + wdw.pix_off * CP;
+    float *o = out + wdw.pix_off * CP;
+    const int n = AXIS == 1 ? wdw.h : (AXIS == 2 ? wdw.w : 1);
+    const long long stride = AXIS == 1 ? (long long)wdw.w * CP : (long long)CP;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+        const int pos = AXIS == 1 ? (int)(i / stride) : (AXIS == 2 ? (int)((i / CP) % wdw.w) : 0);
+        const float *line = a + (i - (long long)pos * stride);   // element 0 of this element's line
+        double tmp = (double)a[i] * w[0];
+        for (int j = r; j >= 1; --j) {
+            int lo = pos - j, hi = pos + j;
+            if (AXIS == 0) { lo = 0; hi = 0; }
+            else {
+                const int per = 2 * n;
+                lo %= per; if (lo < 0) lo += per; if (lo >= n) lo = per - 1 - lo;
+                hi %= per; if (hi >= n) hi = per - 1 - hi;
+            }
+            tmp += ((double)line[(long long)lo * stride] + (double)line[(long long)hi * stride]) * w[j];
+        }
+        o[i] = (float)tmp;
+    }
+}
+
+// NumPy's float64 pairwise summation (blocks of eight accumulators up to 128 elements, halves above): the weights are divided by
+// `phi.sum()`, and the order of the additions decides its last bit
+static double np_pairwise_sum(const double *a, size_t n) {
+    if (n < 8) { double r = 0.0; for (size_t i = 0; i < n; ++i) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        size_t i = 8;
+        for (; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// scratch arrays and the three weight tables (scipy _gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), x = -r..r, r = int(4 sigma + 0.5))
+int smooth_prepare(obia_ctx *ctx, SmoothSpec &sm, long long total_pix, long long maxpix, int CP, int np) {
+    if (!sm.on()) return OBIA_OK;
+    Arena &A = ctx->arena;
+    sm.tmp_a = A.get<float>((size_t)total_pix * CP);
+    sm.tmp_b = A.get<float>((size_t)total_pix * CP);
+    sm.d_scratch = A.get<unsigned>((size_t)np);
+    sm.maxpix = maxpix;
+    if (!sm.tmp_a || !sm.tmp_b || !sm.d_scratch) return OBIA_E_NOMEM;
+    for (int ax = 0; ax < 3; ++ax) {
+        if (!(sm.sigma[ax] > 1e-15)) continue;
+        if (!(sm.sigma[ax] < 1.0e6)) { set_error("sigma %g not supported", sm.sigma[ax]); return OBIA_E_INVALID; }
+        const double sd = sm.sigma[ax];
+        const int r = (int)(4.0 * sd + 0.5);
+        std::vector<double> phi((size_t)2 * r + 1);
+        for (int x = -r; x <= r; ++x) phi[(size_t)(x + r)] = std::exp(-0.5 / (sd * sd) * (double)((long long)x * x));
+        const double sum = np_pairwise_sum(phi.data(), phi.size());
+        std::vector<double> w((size_t)r + 1);
+        for (int j = 0; j <= r; ++j) w[(size_t)j] = phi[(size_t)(r + j)] / sum;
+        sm.radius[ax] = r;
+        sm.d_w[ax] = A.get<double>((size_t)r + 1);
+        if (!sm.d_w[ax]) return OBIA_E_NOMEM;
+        OBIA_TRY(upload_async(ctx, sm.d_w[ax], w.data(), sizeof(double) * w.size()));
+    }
+    return OBIA_OK;
+}
+
 // Launch half of the feature pass on `stream`: min / max of every band of every window, then the features.
 // d_keys layout for np windows: keys[np][C][2] (min, max as ordered uints) | nonfinite[np] | max|feature| bits [np].
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
-                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes, float *d_fbox) {
+                         int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes, float *d_fbox,
+                         const SmoothSpec *smooth) {
     if (C < 1 || C > 16) { set_error("band count %d not supported (1..16)", C); return OBIA_E_UNSUPPORTED; }
     const size_t nkeys = (size_t)np * C * 2, ntot = nkeys + 2 * (size_t)np;
     unsigned *d_nonfinite = d_keys + nkeys, *d_maxabs = d_nonfinite + np;
@@ -387,12 +468,41 @@ int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWin
     const bool box = planes && d_fbox != nullptr;   // colour boxes from the same pass (a block walks footprint bands of 16 rows)
     const int rows = box ? (maxh + 15) / 16 : (planes ? (maxh + 3) / 4 : maxh);
     dim3 grid(rows < 4096 ? rows : 4096, np);
+    // Smoothing: normalise -> Lab (unscaled, pixel-major) -> the Gaussian passes -> scale + plane layout from the smoothed arrays
+    const bool smoothing = smooth && smooth->on();
+    if (smoothing && !planes) { set_error("Gaussian pre-smoothing is built for the SLIC feature layout only"); return OBIA_E_UNSUPPORTED; }
+    const float *planes_src = src;
+    int planes_norm = normalize, planes_lab = to_lab, dense = 0;
+    if (smoothing) {
+        OBIA_HIP_TRY(hipMemsetAsync(smooth->d_scratch, 0, sizeof(unsigned) * (size_t)np, stream));
+        dim3 g1(maxh < 4096 ? maxh : 4096, np);
+#define LAUNCH_UNSCALED(CPV) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), g1, dim3(256), 0, stream, src, Ws, C, d_windows, \
+                                                d_keys, normalize, to_lab, 1.0f, smooth->tmp_a, smooth->d_scratch)
+        switch (CP) {
+            case 4: LAUNCH_UNSCALED(4); break;
+            case 8: LAUNCH_UNSCALED(8); break;
+            case 12: LAUNCH_UNSCALED(12); break;
+            default: LAUNCH_UNSCALED(16); break;
+        }
+#undef LAUNCH_UNSCALED
+        float *cur = smooth->tmp_a, *oth = smooth->tmp_b;
+        long long nb = (smooth->maxpix * CP + 255) / 256;
+        dim3 gg((unsigned)(nb < 65535 ? (nb < 1 ? 1 : nb) : 65535), np);
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!(smooth->sigma[ax] > 1e-15)) continue;
+            if (ax == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gauss_axis_kernel<0>), gg, dim3(256), 0, stream, d_windows, cur, oth, CP, smooth->d_w[0], smooth->radius[0]);
+            else if (ax == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(gauss_axis_kernel<1>), gg, dim3(256), 0, stream, d_windows, cur, oth, CP, smooth->d_w[1], smooth->radius[1]);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(gauss_axis_kernel<2>), gg, dim3(256), 0, stream, d_windows, cur, oth, CP, smooth->d_w[2], smooth->radius[2]);
+            std::swap(cur, oth);
+        }
+        planes_src = cur; planes_norm = 0; planes_lab = 0; dense = 1;
+    }
 #define LAUNCH_FEAT(CPV)                                                                                                  \
     do {                                                                                                                  \
-        if (box) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV, true>), grid, dim3(256), 0, stream, src, Ws, C, \
-                                    d_windows, d_keys, normalize, to_lab, ratio, d_feat, d_maxabs, d_fbox);               \
-        else if (planes) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV, false>), grid, dim3(256), 0, stream, src, Ws, C, \
-                                       d_windows, d_keys, normalize, to_lab, ratio, d_feat, d_maxabs, (float *)nullptr);  \
+        if (box) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV, true>), grid, dim3(256), 0, stream, planes_src, Ws, C, \
+                                    d_windows, d_keys, planes_norm, planes_lab, ratio, d_feat, d_maxabs, d_fbox, dense);  \
+        else if (planes) hipLaunchKernelGGL(HIP_KERNEL_NAME(features_planes_kernel<CPV, false>), grid, dim3(256), 0, stream, planes_src, Ws, C, \
+                                       d_windows, d_keys, planes_norm, planes_lab, ratio, d_feat, d_maxabs, (float *)nullptr, dense); \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(features_kernel<CPV>), grid, dim3(256), 0, stream, src, Ws, C, d_windows,  \
                                 d_keys, normalize, to_lab, ratio, d_feat, d_maxabs);                                      \
     } while (0)
@@ -463,9 +573,13 @@ int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs,
     unsigned *d_keys = ctx->arena.get<unsigned>(ntot);
     if (!d_keys) return OBIA_E_NOMEM;
     int maxh = 1;
-    for (auto &w : b.windows) if (w.h > maxh) maxh = w.h;
+    long long maxpix = 1;
+    for (auto &w : b.windows) { if (w.h > maxh) maxh = w.h; if ((long long)w.h * w.w > maxpix) maxpix = (long long)w.h * w.w; }
+    SmoothSpec sm;
+    for (int i = 0; i < 3; ++i) sm.sigma[i] = b.sigma[i];
+    OBIA_TRY(smooth_prepare(ctx, sm, b.total_pix, maxpix, b.CP, np));
     OBIA_TRY(slic_features_launch(ctx->stream, C, b.CP, np, b.d_windows, maxh, src, Ws, normalize, to_lab, ratio, b.d_feat, d_keys,
-                                  b.feat_planes, (b.col_lb && b.feat_planes) ? b.d_fbox : nullptr));
+                                  b.feat_planes, (b.col_lb && b.feat_planes) ? b.d_fbox : nullptr, &sm));
     // one read-back: min/max keys (constant-band check), non-finite flags, max|feature| per window
     std::vector<unsigned> host(ntot);
     OBIA_TRY(read_back(ctx, host.data(), d_keys, ntot * sizeof(unsigned)));

@@ -84,6 +84,7 @@ struct SlicBatch {
     bool col_lb = false;               // the sweeps add the colour-box bound to the spatial one (see slic_use_colour_bound)
     float *d_feat = nullptr;           // quad-row planes, 4 * total_feat_f4 floats (pixel-major [total_pix][CP] when !feat_planes)
     bool feat_planes = true;           // false: pixel-major features (quickshift reads them per pixel)
+    double sigma[3] = {0.0, 0.0, 0.0};   // Gaussian pre-smoothing (z, y, x), 0 = none (obia_slic_params::sigma_zyx)
     long long total_feat_f4 = 0;       // float4 elements of d_feat (plane layout)
     uint8_t *d_mask = nullptr;         // [total_pix] or null
     int32_t *d_labels = nullptr;       // [total_pix] problem-local labels (start_label based)
@@ -105,9 +106,23 @@ struct SlicBatch {
 // `skip` (nullable): when given, a problem whose window holds a constant or non-finite band is flagged
 // skip[p] = 1 (its features are zero) instead of failing the whole batch -- the reference's tiler
 // swallows the per-tile ValueError (tiling.py:149-150).
+// Gaussian pre-smoothing of slic(..., sigma=...) (slic_superpixels.py: ndi.gaussian_filter between the Lab conversion and the scaling):
+// sigma per axis (z, y, x; the depth axis has ONE plane and is filtered too, as scipy does), two scratch arrays of total_pix * CP
+// floats, the weights of the three passes on the device (smooth_upload_weights) and a scratch word per window.
+struct SmoothSpec {
+    double sigma[3] = {0.0, 0.0, 0.0};
+    float *tmp_a = nullptr, *tmp_b = nullptr;
+    double *d_w[3] = {nullptr, nullptr, nullptr};   // [radius + 1]: centre first
+    int radius[3] = {0, 0, 0};
+    unsigned *d_scratch = nullptr;                  // [np] (max |feature| of the unscaled pass: not used)
+    long long maxpix = 0;                           // pixels of the largest window
+    bool on() const { return sigma[0] > 1e-15 || sigma[1] > 1e-15 || sigma[2] > 1e-15; }
+};
+int smooth_prepare(obia_ctx *ctx, SmoothSpec &sm, long long total_pix, long long maxpix, int CP, int np);
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
                          int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes = true,
-                         float *d_fbox = nullptr);   // d_fbox (plane layout only): the footprints' colour boxes from the same pass
+                         float *d_fbox = nullptr,    // d_fbox (plane layout only): the footprints' colour boxes from the same pass
+                         const SmoothSpec *smooth = nullptr);
 int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *nonfinite, const unsigned *maxabs_bits, int normalize,
                          std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,

@@ -339,6 +339,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.max_iter = S.sp.max_num_iter;
     b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
     b.slic_zero = S.sp.slic_zero != 0;
+    for (int i = 0; i < 3; ++i) b.sigma[i] = S.sp.sigma_zyx[i];
     long long off = 0, foff = 0, boff = 0, maxpix = 1;
     b.probs.resize(np);
     b.windows.resize(np);
@@ -473,6 +474,7 @@ static int tiler_check(const float *img, int H, int W, int C, int Hg, int row0, 
     if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels: shard it across GPUs"); return OBIA_E_INVALID; }
     if (tp->tile_size <= 0 || tp->buffer < 0) { set_error("tile_size must be positive and buffer non-negative"); return OBIA_E_INVALID; }
     if (!(sp->compactness > 0.0) || sp->max_num_iter < 0) { set_error("bad SLIC parameters"); return OBIA_E_INVALID; }
+    for (int i = 0; i < 3; ++i) if (!(sp->sigma_zyx[i] >= 0.0)) { set_error("sigma must be >= 0"); return OBIA_E_INVALID; }
     if (!sp->enforce_connectivity) { set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)"); return OBIA_E_UNSUPPORTED; }
     if (sp->n_segments <= 0 && !(tp->crown_radius > 0.0 && tp->pixel_width > 0.0 && tp->pixel_height > 0.0)) {
         set_error("crown_radius and pixel size must be positive when n_segments is not given");
@@ -537,6 +539,7 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
     const int ntx = cdiv(S.W, T), nty = cdiv(S.Hg, T);
     TileState::PreFeat &pf = S.pf;
     pf = TileState::PreFeat();
+    if (S.sp.sigma_zyx[0] > 0.0 || S.sp.sigma_zyx[1] > 0.0 || S.sp.sigma_zyx[2] > 0.0) return OBIA_OK;   // Gaussian pre-smoothing: per-batch features (slic_prepare_features holds the smoothing passes)
     for (int cls = 0; cls < (white_order == 1 ? 2 : 1); ++cls)
         for (int tj = 0; tj < nty; ++tj) {
             if (white_order == 1 && (tj & 1) != cls) continue;

@@ -30,7 +30,7 @@ def _is_torch(x):
 
 def make_params(n_segments=100, compactness=10.0, max_num_iter=10, convert2lab=None, enforce_connectivity=True,
                 min_size_factor=0.5, max_size_factor=3, slic_zero=False, start_label=1, normalize_bands=False,
-                exit_on_fixed_point=False):
+                exit_on_fixed_point=False, sigma=0):
     p = _lib.SlicParams()
     p.n_segments = int(n_segments)
     p.compactness = float(compactness)
@@ -43,12 +43,31 @@ def make_params(n_segments=100, compactness=10.0, max_num_iter=10, convert2lab=N
     p.start_label = int(start_label)
     p.normalize_bands = int(bool(normalize_bands))
     p.exit_on_fixed_point = int(bool(exit_on_fixed_point))
+    p.reserved = 0
+    for i, v in enumerate(sigma_zyx(sigma)):
+        p.sigma_zyx[i] = v
     return p
 
 
-def _check_common(sigma, spacing, channel_axis, multichannel):
-    if np.any(np.asarray(sigma) != 0):
-        raise NotImplementedError("sigma != 0 (Gaussian pre-smoothing) is not implemented; obia never sets it")
+def sigma_zyx(sigma):
+    """scikit-image's reading of `sigma` (slic_superpixels.py) with spacing (1, 1, 1): a number is the width on every axis of the
+    (1, H, W, C) image -- the one-plane depth axis included --, a sequence is taken as (depth, row, column)."""
+    if sigma is None:
+        return [0.0, 0.0, 0.0]
+    if np.isscalar(sigma):
+        s = [float(sigma)] * 3
+    else:
+        s = [float(v) for v in sigma]
+        if len(s) != 3:
+            raise ValueError("sigma: a number or a (depth, row, column) sequence of three")
+    if any(not (v >= 0.0) for v in s):
+        raise ValueError("sigma must be >= 0")
+    return s
+
+
+def _check_common(sigma, spacing, channel_axis, multichannel, sigma_ok=False):
+    if not sigma_ok and np.any(np.asarray(sigma) != 0):
+        raise NotImplementedError("sigma != 0 (Gaussian pre-smoothing) is not implemented for this operator; obia never sets it")
     if spacing is not None:
         raise NotImplementedError("spacing is not implemented (2-D rasters only)")
     if channel_axis not in (-1, None, 2):
@@ -77,13 +96,13 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
         work on rasters that converge early (e.g. compactness 10 on [0,1] features).  Not a scikit-image argument.
     Raises ValueError / NotImplementedError like the reference for bad / unsupported arguments.
     """
-    _check_common(sigma, spacing, channel_axis, multichannel)
+    _check_common(sigma, spacing, channel_axis, multichannel, sigma_ok=True)
     if max_iter is not None:            # scikit-image < 0.19 keyword
         max_num_iter = max_iter
     if start_label not in (0, 1):
         raise ValueError("start_label should be 0 or 1.")
     params = make_params(n_segments, compactness, max_num_iter, convert2lab, enforce_connectivity, min_size_factor,
-                         max_size_factor, slic_zero, start_label, _normalize_bands, exit_on_fixed_point)
+                         max_size_factor, slic_zero, start_label, _normalize_bands, exit_on_fixed_point, sigma)
     lib = _lib.load()
     n_out = ctypes.c_int(0)
     if _is_torch(image):

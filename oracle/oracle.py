@@ -83,6 +83,77 @@ def rgb2lab(rgb):
     return out
 
 
+# ---- Gaussian pre-smoothing: slic(..., sigma=...) -----------------------------------------------------------------------
+# slic_superpixels.py (0.18.3): a scalar sigma becomes [s, s, s] / spacing, a sequence is taken as (z, y, x); when any entry is
+# positive  `image = ndi.gaussian_filter(image, list(sigma) + [0])`  on the (1, H, W, C) image -- after the Lab conversion, before
+# `* 1/compactness`.  scipy.ndimage.gaussian_filter (filters.py): one correlate1d per axis with sigma > 1e-15, in axis order, each
+# pass written in the image's dtype (float32 here); weights = exp(-0.5 / sigma^2 * x^2) over x = -r..r, r = int(4 sigma + 0.5),
+# divided by their NumPy sum (pairwise summation).  correlate1d (ni_filters.c, symmetric weights, mode 'reflect' = d c b a | a b c d |
+# d c b a, repeated): the line is read as double,  tmp = line[i] * w[0];  for j = r .. 1: tmp += (line[i - j] + line[i + j]) * w[j].
+# Pinned bit-exactly on scipy's output (tests/golden/sigma*.npz hold `smoothed`).
+def _pairwise_sum(a):
+    n = len(a)
+    if n < 8:
+        res = 0.0
+        for v in a:
+            res += float(v)
+        return res
+    if n <= 128:
+        r = [float(a[j]) for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] += float(a[i + j])
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res += float(a[i])
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return _pairwise_sum(a[:n2]) + _pairwise_sum(a[n2:])
+
+
+def gaussian_weights(sigma, truncate=4.0):
+    sd = float(sigma)
+    lw = int(truncate * sd + 0.5)
+    x = np.arange(-lw, lw + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return phi / _pairwise_sum(phi), lw
+
+
+def _correlate1d_reflect(a, w, lw, axis):
+    a = np.moveaxis(a, axis, -1)
+    n = a.shape[-1]
+    idx = np.mod(np.arange(-lw, n + lw), 2 * n)
+    idx = np.where(idx >= n, 2 * n - 1 - idx, idx)
+    ext = a[..., idx].astype(np.float64)
+    tmp = ext[..., lw:lw + n] * w[lw]
+    for jj in range(-lw, 0):
+        tmp = tmp + (ext[..., lw + jj:lw + jj + n] + ext[..., lw - jj:lw - jj + n]) * w[lw + jj]
+    return np.moveaxis(tmp.astype(a.dtype), -1, axis)
+
+
+def sigma_zyx(sigma):
+    """slic()'s reading of its `sigma` argument with spacing = (1, 1, 1)."""
+    if np.isscalar(sigma):
+        return [float(sigma)] * 3
+    s = [float(v) for v in sigma]
+    if len(s) != 3:
+        raise ValueError("sigma: a number or a (z, y, x) sequence")
+    return s
+
+
+def gaussian_filter_zyx(img_hwc, sigma):
+    out = np.ascontiguousarray(img_hwc, np.float32)[None]           # (1, H, W, C): the depth axis has one plane and is filtered too
+    for ax, s in enumerate(sigma_zyx(sigma)):
+        if s > 1e-15:
+            w, lw = gaussian_weights(s)
+            out = _correlate1d_reflect(out, w, lw, ax)
+    return np.ascontiguousarray(out[0])
+
+
 def slic_core(image_scaled, segments, step, max_iter=10, mask=None, slic_zero=False,
               ignore_color=False, start_label=1):
     """_slic_cython; `segments` (K,2+C) float32 is updated in place. Returns labels (H,W) int64."""
@@ -114,7 +185,7 @@ def enforce_connectivity(labels, min_size, max_size, start_label=1):
 
 def slic(image, n_segments=100, compactness=10.0, max_iter=10, convert2lab=None,
          enforce_connectivity=True, min_size_factor=0.5, max_size_factor=3, slic_zero=False,
-         start_label=1, mask=None, seeds_yx=None, seed_steps=None, return_all=False):
+         start_label=1, mask=None, seeds_yx=None, seed_steps=None, return_all=False, sigma=0):
     """skimage.segmentation.slic for a (H,W,C) float32 image (slic_superpixels.py:107-333).
 
     With ``mask`` and no ``seeds_yx`` the build's masked-grid seeding rule is used (see
@@ -128,6 +199,11 @@ def slic(image, n_segments=100, compactness=10.0, max_iter=10, convert2lab=None,
     if mask is not None:
         mask = np.ascontiguousarray(mask, np.uint8)
     c2l = -1 if convert2lab is None else int(bool(convert2lab))
+    if any(v > 0 for v in sigma_zyx(sigma)):   # smoothing sits between the Lab conversion and the scaling: Lab here, the rest in C
+        if C == 3 and c2l != 0:
+            image = rgb2lab(image)
+        image = gaussian_filter_zyx(image, sigma)
+        c2l = 0
     labels = np.empty((H, W), np.int64)
     pre = np.empty((H, W), np.int64)
     if seeds_yx is not None:

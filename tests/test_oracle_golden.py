@@ -17,7 +17,8 @@ from tests.metrics import adjusted_rand_index, label_disagreement
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_", "sigma")))
+SIGMA_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "sigma*.npz")))
 
 
 def load(name):
@@ -52,6 +53,39 @@ def test_slic_labels_match_skimage(oracle, name):
     else:
         assert np.array_equal(pre, z["labels_pre"]), f"pre-connectivity labels differ: {(pre != z['labels_pre']).sum()} px"
         assert np.array_equal(labels, z["labels"]), f"final labels differ: {(labels != z['labels']).sum()} px"
+
+
+@pytest.mark.parametrize("name", SIGMA_CASES)
+def test_slic_with_sigma_matches_skimage(oracle, name):
+    """slic(..., sigma=...): the Gaussian pre-smoothing (scipy.ndimage.gaussian_filter between the Lab conversion and the scaling) --
+    the smoothed image bit for bit (Lab rasters: within the Lab tolerance), the labels as in the unsmoothed cases.
+    Fixtures: tests/golden/gen_goldens_sigma.py (scikit-image 0.18.3, SciPy 1.7.1)."""
+    z, params = load(name)
+    img = oracle.normalize(z["raw"].astype(np.float32))
+    sig = [float(v) for v in z["sigma_zyx"]]
+    lab_case = z["raw"].shape[2] == 3 and params.get("convert2lab", None) is not False
+    sm = oracle.gaussian_filter_zyx(oracle.rgb2lab(img) if lab_case else img, sig)
+    if lab_case:
+        assert np.abs(sm - z["smoothed"]).max() <= 2e-4
+    else:
+        assert np.array_equal(sm, z["smoothed"])
+    kw = dict(n_segments=params["n_segments"], compactness=params["compactness"], sigma=sig)
+    if "mask" in z.files:
+        kw.update(mask=z["mask"], seeds_yx=z["seeds_yx"], seed_steps=z["seed_steps"])
+    labels, pre, _ = oracle.slic(img, return_all=True, **kw)
+    if lab_case:
+        assert label_disagreement(pre, z["labels_pre"]) <= 2e-4
+        assert adjusted_rand_index(labels, z["labels"]) >= 0.995
+    else:
+        assert np.array_equal(pre, z["labels_pre"]) and np.array_equal(labels, z["labels"])
+
+
+def test_gaussian_weights_sum_like_numpy(oracle):
+    """the weights are normalised by NumPy's pairwise sum, restated in `_pairwise_sum` (the order of the additions decides the last bit)"""
+    rs = np.random.RandomState(0)
+    for n in (1, 5, 7, 8, 9, 17, 97, 128, 129, 200, 1000):
+        a = rs.rand(n)
+        assert oracle._pairwise_sum(a) == float(np.sum(a)), n
 
 
 def test_rgb2lab_close_to_skimage(oracle):
