@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OBIA_ABI_VERSION 2   /* 2 (round 3): obia_slic_params grew sigma_zyx */
+#define OBIA_ABI_VERSION 2   /* 2 (round 3): obia_slic_params grew sigma_zyx, spacing_zyx */
 
 #define OBIA_OK 0
 #define OBIA_E_INVALID (-1)     /* bad argument (Python side raises ValueError)                     */
@@ -78,8 +78,12 @@ typedef struct obia_slic_params {
                                       (1, H, W, C) image slic() builds -- scipy.ndimage.gaussian_filter, mode 'reflect',
                                       truncate 4, applied after the Lab conversion and before `* 1/compactness`
                                       (slic_superpixels.py; a scalar `sigma` is the same value three times: the one-plane
-                                      depth axis is filtered too).  0 = none, the default.  `spacing` is not supported
-                                      (2-D rasters: it only matters for volumes).                                      */
+                                      depth axis is filtered too).  0 = none, the default.  A caller that mirrors slic()
+                                      divides a SCALAR sigma by the spacing first and passes a sequence as it is.       */
+    double spacing_zyx[3];         /* scikit-image `spacing`: voxel size per axis (depth, row, column); the row / column
+                                      differences are scaled by it before they are squared (_slic.pyx: dy = (sy * (cy - y))^2).
+                                      (1, 1, 1) = the default.  Anything else takes the direct (unstaged) sweep path: exact,
+                                      not tuned -- anisotropic pixels are rare in rasters.                              */
 } obia_slic_params;
 
 void obia_slic_default_params(obia_slic_params *p);

@@ -24,7 +24,7 @@ class SlicParams(ctypes.Structure):
                 ("enforce_connectivity", ctypes.c_int32), ("slic_zero", ctypes.c_int32),
                 ("start_label", ctypes.c_int32), ("normalize_bands", ctypes.c_int32),
                 ("exit_on_fixed_point", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("sigma_zyx", ctypes.c_double * 3)]
+                ("sigma_zyx", ctypes.c_double * 3), ("spacing_zyx", ctypes.c_double * 3)]
 
 
 class SlicSeeds(ctypes.Structure):

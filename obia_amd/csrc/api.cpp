@@ -24,8 +24,10 @@ int check_slic_args(const float *img, int H, int W, int C, const obia_slic_param
     if (!(p->compactness > 0.0)) { set_error("compactness must be positive"); return OBIA_E_INVALID; }
     if (p->n_segments <= 0) { set_error("n_segments must be positive"); return OBIA_E_INVALID; }
     if (p->max_num_iter < 0) { set_error("max_num_iter must be >= 0"); return OBIA_E_INVALID; }
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
         if (!(p->sigma_zyx[i] >= 0.0)) { set_error("sigma must be >= 0"); return OBIA_E_INVALID; }
+        if (!(p->spacing_zyx[i] > 0.0) || !(p->spacing_zyx[i] < 1.0e30)) { set_error("spacing must be positive and finite"); return OBIA_E_INVALID; }
+    }
     return OBIA_OK;
 }
 
@@ -41,7 +43,9 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.max_iter = p->max_num_iter;
     b.exit_on_fixed_point = p->exit_on_fixed_point != 0;
     b.slic_zero = p->slic_zero != 0;
-    for (int i = 0; i < 3; ++i) b.sigma[i] = p->sigma_zyx[i];
+    for (int i = 0; i < 3; ++i) { b.sigma[i] = p->sigma_zyx[i]; b.spacing[i] = p->spacing_zyx[i]; }
+    const bool direct = (float)b.spacing[1] != 1.0f || (float)b.spacing[2] != 1.0f;   // anisotropic spacing: the direct sweep path (slic_sweep.hip)
+    if (direct) b.exit_on_fixed_point = false;
     b.total_pix = (long long)H * W;
     SlicProblem P{};
     P.H = H; P.W = W; P.pix_off = 0; P.feat_off = 0; P.XB = feat_xb(W); P.fb_off = 0;
@@ -56,7 +60,7 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
     b.d_mask = const_cast<uint8_t *>(mask);
     const int to_lab = (C == 3 && p->convert2lab != 0) ? 1 : 0;
     const float ratio = (float)(1.0 / p->compactness);   // `image * ratio`: float32 array times Python float
-    b.col_lb = slic_use_colour_bound(ratio, to_lab != 0) && !b.slic_zero && !b.exit_on_fixed_point;
+    b.col_lb = slic_use_colour_bound(ratio, to_lab != 0) && !b.slic_zero && !b.exit_on_fixed_point && !direct;
     if (b.col_lb) {
         b.d_fbox = A.get<float>((size_t)feat_boxes(H, W) * 2 * b.CP);
         if (!b.d_fbox) return OBIA_E_NOMEM;

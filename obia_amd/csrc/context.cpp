@@ -315,6 +315,7 @@ void obia_slic_default_params(obia_slic_params *p) {
     p->exit_on_fixed_point = 0;
     p->reserved = 0;
     p->sigma_zyx[0] = p->sigma_zyx[1] = p->sigma_zyx[2] = 0.0;
+    p->spacing_zyx[0] = p->spacing_zyx[1] = p->spacing_zyx[2] = 1.0;
 }
 
 int obia_set_profiling(obia_ctx *ctx, int enabled) {

@@ -430,10 +430,13 @@ int smooth_prepare(obia_ctx *ctx, SmoothSpec &sm, long long total_pix, long long
     for (int ax = 0; ax < 3; ++ax) {
         if (!(sm.sigma[ax] > 1e-15)) continue;
         if (!(sm.sigma[ax] < 1.0e6)) { set_error("sigma %g not supported", sm.sigma[ax]); return OBIA_E_INVALID; }
-        const double sd = sm.sigma[ax];
+        // the sigma slic() hands scipy is a float32 (the image's dtype); scipy forms sigma * sigma in float32, the rest in double
+        const float s32 = (float)sm.sigma[ax];
+        const double sd = (double)s32;
         const int r = (int)(4.0 * sd + 0.5);
+        const double sigma2 = (double)(s32 * s32);
         std::vector<double> phi((size_t)2 * r + 1);
-        for (int x = -r; x <= r; ++x) phi[(size_t)(x + r)] = std::exp(-0.5 / (sd * sd) * (double)((long long)x * x));
+        for (int x = -r; x <= r; ++x) phi[(size_t)(x + r)] = std::exp(-0.5 / sigma2 * (double)((long long)x * x));
         const double sum = np_pairwise_sum(phi.data(), phi.size());
         std::vector<double> w((size_t)r + 1);
         for (int j = 0; j <= r; ++j) w[(size_t)j] = phi[(size_t)(r + j)] / sum;
@@ -847,6 +850,9 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         P.ncx = cdiv(P.W, P.sx);
         const float stepf = (float)stepmax[p];
         P.spatial_w = (float)(1.0 / ((double)stepf * (double)stepf));
+        P.sp_y = (float)b.spacing[1]; P.sp_x = (float)b.spacing[2];   // np.ascontiguousarray(spacing, dtype=image dtype)
+        P.direct = (P.sp_y != 1.0f || P.sp_x != 1.0f) ? 1 : 0;
+        P.pad_ = 0;
         P.cell_off = cell_off;
         long long nc = (long long)P.ncy * P.ncx;
         if (cell_off + nc > 0x7fff0000LL) { set_error("too many bins in one batch"); return OBIA_E_INVALID; }

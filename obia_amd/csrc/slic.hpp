@@ -21,6 +21,9 @@ struct SlicProblem {
     int XB;              // 16-column blocks per row of the feature planes: ceil(W / 16)
     int n_valid;         // valid (unmasked) pixels
     long long fb_off;    // first record of this problem in the footprint colour boxes (SlicBatch::d_fbox)
+    float sp_y, sp_x;    // slic()'s `spacing` of the row / column axis as float32 (1, 1 unless the caller says otherwise)
+    int direct;          // 1: every tile takes the direct (unstaged) path -- set when the spacing is not (1, 1)
+    int pad_;
 };
 
 // Source window of a problem inside the caller's raster (feature preparation).
@@ -85,6 +88,7 @@ struct SlicBatch {
     float *d_feat = nullptr;           // quad-row planes, 4 * total_feat_f4 floats (pixel-major [total_pix][CP] when !feat_planes)
     bool feat_planes = true;           // false: pixel-major features (quickshift reads them per pixel)
     double sigma[3] = {0.0, 0.0, 0.0};   // Gaussian pre-smoothing (z, y, x), 0 = none (obia_slic_params::sigma_zyx)
+    double spacing[3] = {1.0, 1.0, 1.0}; // obia_slic_params::spacing_zyx
     long long total_feat_f4 = 0;       // float4 elements of d_feat (plane layout)
     uint8_t *d_mask = nullptr;         // [total_pix] or null
     int32_t *d_labels = nullptr;       // [total_pix] problem-local labels (start_label based)

@@ -374,7 +374,8 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
                     const float *rec = cent + (size_t)cur * RS;
                     const int *irec = reinterpret_cast<const int *>(rec);
                     if (!(y >= irec[2] && y < irec[3] && x >= irec[4] && x < irec[5])) continue;
-                    const float tyv = rec[0] - (float)y, txv = rec[1] - (float)x;
+                    // (`spacing`: the differences are scaled before they are squared, _slic.pyx; (1, 1) multiplies by 1.0f -- exact)
+                    const float tyv = P.sp_y * (rec[0] - (float)y), txv = P.sp_x * (rec[1] - (float)x);
                     const float dy2 = tyv * tyv, dx2 = txv * txv;
                     float d = (dy2 + dx2) * w;
                     if (!IGNORE_COLOR) {
@@ -494,6 +495,12 @@ __device__ __forceinline__ void slic_assign_body(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it lives in scalar registers
     const int ty0 = (tile / P.tiles_x) * SWEEP_TH, tx0 = (tile % P.tiles_x) * SWEEP_TW;
     const int ty1 = min(ty0 + SWEEP_TH, P.H), tx1 = min(tx0 + SWEEP_TW, P.W);
+    if (P.direct) {   // anisotropic `spacing`: every tile takes the direct path (same arithmetic with the scaled differences; the staged
+                      // path's bounds and packed distance code assume unit spacing).  Workgroup-uniform.
+        slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
+                                                      accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
+        return;
+    }
 
     // ---- wave geometry; the features of the wave's FIRST footprint are requested before staging, so their HBM
     // latency overlaps the dependent bin -> record loads of the staging phase ---------------------------------------

@@ -339,7 +339,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.max_iter = S.sp.max_num_iter;
     b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
     b.slic_zero = S.sp.slic_zero != 0;
-    for (int i = 0; i < 3; ++i) b.sigma[i] = S.sp.sigma_zyx[i];
+    for (int i = 0; i < 3; ++i) { b.sigma[i] = S.sp.sigma_zyx[i]; b.spacing[i] = S.sp.spacing_zyx[i]; }
+    const bool direct = (float)b.spacing[1] != 1.0f || (float)b.spacing[2] != 1.0f;   // anisotropic spacing: the direct sweep path
+    if (direct) b.exit_on_fixed_point = false;
     long long off = 0, foff = 0, boff = 0, maxpix = 1;
     b.probs.resize(np);
     b.windows.resize(np);
@@ -356,7 +358,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         boff += feat_boxes(wins[p].h, wins[p].w);
     }
     b.total_feat_f4 = foff;
-    b.col_lb = slic_use_colour_bound((float)(1.0 / S.sp.compactness), S.C == 3 && S.sp.convert2lab != 0) && !b.slic_zero && !b.exit_on_fixed_point;
+    b.col_lb = slic_use_colour_bound((float)(1.0 / S.sp.compactness), S.C == 3 && S.sp.convert2lab != 0) && !b.slic_zero && !b.exit_on_fixed_point && !direct;
     if (off > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
     b.total_pix = off;
     TileWin *d_wins = A.get<TileWin>(np);
@@ -474,7 +476,10 @@ static int tiler_check(const float *img, int H, int W, int C, int Hg, int row0, 
     if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels: shard it across GPUs"); return OBIA_E_INVALID; }
     if (tp->tile_size <= 0 || tp->buffer < 0) { set_error("tile_size must be positive and buffer non-negative"); return OBIA_E_INVALID; }
     if (!(sp->compactness > 0.0) || sp->max_num_iter < 0) { set_error("bad SLIC parameters"); return OBIA_E_INVALID; }
-    for (int i = 0; i < 3; ++i) if (!(sp->sigma_zyx[i] >= 0.0)) { set_error("sigma must be >= 0"); return OBIA_E_INVALID; }
+    for (int i = 0; i < 3; ++i) {
+        if (!(sp->sigma_zyx[i] >= 0.0)) { set_error("sigma must be >= 0"); return OBIA_E_INVALID; }
+        if (!(sp->spacing_zyx[i] > 0.0) || !(sp->spacing_zyx[i] < 1.0e30)) { set_error("spacing must be positive and finite"); return OBIA_E_INVALID; }
+    }
     if (!sp->enforce_connectivity) { set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)"); return OBIA_E_UNSUPPORTED; }
     if (sp->n_segments <= 0 && !(tp->crown_radius > 0.0 && tp->pixel_width > 0.0 && tp->pixel_height > 0.0)) {
         set_error("crown_radius and pixel size must be positive when n_segments is not given");
@@ -570,7 +575,8 @@ static int prefetch_white_plan(obia_ctx *ctx, TileState &S, int white_order) {
     pf.d_keys = A.get<unsigned>(ntot);
     pf.d_feat = A.get<float>(4 * (size_t)foff);
     if (!pf.d_windows || !pf.d_keys || !pf.d_feat) return OBIA_E_NOMEM;
-    if (slic_use_colour_bound((float)(1.0 / S.sp.compactness), S.C == 3 && S.sp.convert2lab != 0) && !S.sp.slic_zero && !S.sp.exit_on_fixed_point) {
+    if (slic_use_colour_bound((float)(1.0 / S.sp.compactness), S.C == 3 && S.sp.convert2lab != 0) && !S.sp.slic_zero && !S.sp.exit_on_fixed_point &&
+        (float)S.sp.spacing_zyx[1] == 1.0f && (float)S.sp.spacing_zyx[2] == 1.0f) {
         pf.d_fbox = A.get<float>((size_t)boff * 2 * CP);
         if (!pf.d_fbox) return OBIA_E_NOMEM;
     }

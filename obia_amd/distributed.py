@@ -49,11 +49,11 @@ class HipTilerEngine:
                                   min_size_factor=slic_kwargs.get("min_size_factor", 0.5),
                                   max_size_factor=slic_kwargs.get("max_size_factor", 3),
                                   slic_zero=slic_kwargs.get("slic_zero", False), start_label=1, normalize_bands=True,
-                                  exit_on_fixed_point=slic_kwargs.get("exit_on_fixed_point", False), sigma=slic_kwargs.get("sigma", 0))
+                                  exit_on_fixed_point=slic_kwargs.get("exit_on_fixed_point", False), sigma=slic_kwargs.get("sigma", 0), spacing=slic_kwargs.get("spacing"))
         if not slic_kwargs.get("enforce_connectivity", True):
             raise NotImplementedError("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)")
         unknown = [k for k in slic_kwargs if k not in ("n_segments", "compactness", "max_num_iter", "convert2lab", "min_size_factor",
-                                                      "max_size_factor", "slic_zero", "exit_on_fixed_point", "enforce_connectivity", "sigma")]
+                                                      "max_size_factor", "slic_zero", "exit_on_fixed_point", "enforce_connectivity", "sigma", "spacing")]
         if unknown:
             raise TypeError(f"slic() got an unexpected keyword argument '{unknown[0]}'")
         self.tp = _lib.TilingParams()

@@ -30,7 +30,7 @@ def _is_torch(x):
 
 def make_params(n_segments=100, compactness=10.0, max_num_iter=10, convert2lab=None, enforce_connectivity=True,
                 min_size_factor=0.5, max_size_factor=3, slic_zero=False, start_label=1, normalize_bands=False,
-                exit_on_fixed_point=False, sigma=0):
+                exit_on_fixed_point=False, sigma=0, spacing=None):
     p = _lib.SlicParams()
     p.n_segments = int(n_segments)
     p.compactness = float(compactness)
@@ -44,32 +44,48 @@ def make_params(n_segments=100, compactness=10.0, max_num_iter=10, convert2lab=N
     p.normalize_bands = int(bool(normalize_bands))
     p.exit_on_fixed_point = int(bool(exit_on_fixed_point))
     p.reserved = 0
-    for i, v in enumerate(sigma_zyx(sigma)):
+    for i, v in enumerate(sigma_zyx(sigma, spacing)):
         p.sigma_zyx[i] = v
+    for i, v in enumerate(spacing_zyx(spacing)):
+        p.spacing_zyx[i] = v
     return p
 
 
-def sigma_zyx(sigma):
-    """scikit-image's reading of `sigma` (slic_superpixels.py) with spacing (1, 1, 1): a number is the width on every axis of the
-    (1, H, W, C) image -- the one-plane depth axis included --, a sequence is taken as (depth, row, column)."""
+def spacing_zyx(spacing):
+    """scikit-image's `spacing` (voxel size per axis: depth, row, column) in the image's dtype, float32."""
+    if spacing is None:
+        return [1.0, 1.0, 1.0]
+    s = np.ascontiguousarray(spacing, dtype=np.float32).ravel()
+    if s.shape != (3,):
+        raise ValueError("spacing: a (depth, row, column) sequence of three")
+    if not np.all(np.isfinite(s)) or np.any(s <= 0):
+        raise ValueError("spacing must be positive and finite")
+    return [float(v) for v in s]
+
+
+def sigma_zyx(sigma, spacing=None):
+    """scikit-image's reading of `sigma` (slic_superpixels.py): the widths live in the image's dtype (float32); a number is the width on
+    every axis of the (1, H, W, C) image -- the one-plane depth axis included -- DIVIDED by the spacing, a sequence is taken as
+    (depth, row, column) as it is."""
     if sigma is None:
         return [0.0, 0.0, 0.0]
     if np.isscalar(sigma):
-        s = [float(sigma)] * 3
+        s = np.array([sigma, sigma, sigma], dtype=np.float32)
+        s /= np.asarray(spacing_zyx(spacing), np.float32)
     else:
-        s = [float(v) for v in sigma]
-        if len(s) != 3:
+        s = np.array(sigma, dtype=np.float32).ravel()
+        if s.shape != (3,):
             raise ValueError("sigma: a number or a (depth, row, column) sequence of three")
-    if any(not (v >= 0.0) for v in s):
+    if not np.all(s >= 0):
         raise ValueError("sigma must be >= 0")
-    return s
+    return [float(v) for v in s]
 
 
 def _check_common(sigma, spacing, channel_axis, multichannel, sigma_ok=False):
     if not sigma_ok and np.any(np.asarray(sigma) != 0):
         raise NotImplementedError("sigma != 0 (Gaussian pre-smoothing) is not implemented for this operator; obia never sets it")
-    if spacing is not None:
-        raise NotImplementedError("spacing is not implemented (2-D rasters only)")
+    if not sigma_ok and spacing is not None:
+        raise NotImplementedError("spacing is not implemented for this operator")
     if channel_axis not in (-1, None, 2):
         raise NotImplementedError("channel_axis must be -1 (band-interleaved (H,W,C) rasters)")
     if multichannel is not None and not multichannel:
@@ -102,7 +118,7 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
     if start_label not in (0, 1):
         raise ValueError("start_label should be 0 or 1.")
     params = make_params(n_segments, compactness, max_num_iter, convert2lab, enforce_connectivity, min_size_factor,
-                         max_size_factor, slic_zero, start_label, _normalize_bands, exit_on_fixed_point, sigma)
+                         max_size_factor, slic_zero, start_label, _normalize_bands, exit_on_fixed_point, sigma, spacing)
     lib = _lib.load()
     n_out = ctypes.c_int(0)
     if _is_torch(image):

@@ -96,8 +96,6 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
         pw, ph = float(pixel_size[0]), float(pixel_size[1])
     if pw is None:
         pw = ph = 1.0
-    if kwargs.get("spacing") is not None:
-        raise NotImplementedError("spacing is not implemented (2-D rasters only)")
     n_seg = kwargs.get("n_segments", None)
     params = make_params(n_segments=0 if n_seg is None else n_seg, compactness=kwargs.get("compactness", 10.0),
                          max_num_iter=kwargs.get("max_num_iter", kwargs.get("max_iter", 10) or 10),
@@ -106,7 +104,7 @@ def create_tiled_segments(input_raster, output_dir=None, input_mask=None, method
                          min_size_factor=kwargs.get("min_size_factor", 0.5),
                          max_size_factor=kwargs.get("max_size_factor", 3), slic_zero=kwargs.get("slic_zero", False),
                          start_label=1, normalize_bands=True, exit_on_fixed_point=kwargs.get("exit_on_fixed_point", False),
-                         sigma=kwargs.get("sigma", 0))
+                         sigma=kwargs.get("sigma", 0), spacing=kwargs.get("spacing"))
     if white_order not in ("raster", "parity"):
         raise ValueError("white_order must be 'raster' or 'parity'")
     tp = _lib.TilingParams()

@@ -196,10 +196,23 @@ int64_t obia_oracle_grid_centroids(int64_t H, int64_t W, int64_t n_segments, int
  *   nearest (H,W) int64 out
  * Window steps come from regular_grid((1,H,W), K) with K = number of centroids.
  * ------------------------------------------------------------------------------------------ */
+/* spacing (sy, sx): _slic.pyx scales the coordinate differences before squaring them, `dy = (sy * (cy - y)) ** 2` in the image's
+ * float type (the depth term is (sz * 0) ** 2 = 0 whatever sz); (1, 1) multiplies by 1.0f, which is exact. */
+int obia_oracle_slic_core_sp(const float *image, const uint8_t *mask, float *segments,
+                             int64_t H, int64_t W, int C, int64_t K, float step,
+                             int max_iter, int slic_zero, int ignore_color, int start_label,
+                             int64_t *nearest, float sy, float sx);
 int obia_oracle_slic_core(const float *image, const uint8_t *mask, float *segments,
                           int64_t H, int64_t W, int C, int64_t K, float step,
                           int max_iter, int slic_zero, int ignore_color, int start_label,
                           int64_t *nearest)
+{
+    return obia_oracle_slic_core_sp(image, mask, segments, H, W, C, K, step, max_iter, slic_zero, ignore_color, start_label, nearest, 1.0f, 1.0f);
+}
+int obia_oracle_slic_core_sp(const float *image, const uint8_t *mask, float *segments,
+                             int64_t H, int64_t W, int C, int64_t K, float step,
+                             int max_iter, int slic_zero, int ignore_color, int start_label,
+                             int64_t *nearest, float sy, float sx)
 {
     int64_t g[4];
     obia_oracle_regular_grid(H, W, K, g);
@@ -229,10 +242,12 @@ int obia_oracle_slic_core(const float *image, const uint8_t *mask, float *segmen
             const int64_t y0 = (int64_t)fy0, y1 = (int64_t)fy1, x0 = (int64_t)fx0, x1 = (int64_t)fx1;
             for (int64_t y = y0; y < y1; ++y) {
                 float ty = cy - (float)y;
+                ty = sy * ty;
                 const float dy = ty * ty;
                 for (int64_t x = x0; x < x1; ++x) {
                     if (mask && !mask[y * W + x]) continue;
                     float tx = cx - (float)x;
+                    tx = sx * tx;
                     const float dx = tx * tx;
                     float d = (dy + dx) * spatial_weight;
                     if (!ignore_color) {
@@ -394,6 +409,12 @@ int64_t obia_oracle_masked_grid_centroids(const uint8_t *mask, int64_t H, int64_
  *   labels_pre (nullable) receives the labels before connectivity enforcement.
  *   centroids_out (nullable, K*(2+C)) receives the final centroids; *K_out the centroid count.
  * ------------------------------------------------------------------------------------------ */
+int obia_oracle_slic_sp(const float *image, const uint8_t *mask, int64_t H, int64_t W, int C,
+                        int64_t n_segments, double compactness, int max_iter, int convert2lab,
+                        int enforce_connectivity, double min_size_factor, double max_size_factor,
+                        int slic_zero, int start_label,
+                        const double *seeds_yx, int64_t n_seeds, const double *seed_steps,
+                        int64_t *labels, int64_t *labels_pre, float *centroids_out, int64_t *K_out, const double *spacing_yx);
 int obia_oracle_slic(const float *image, const uint8_t *mask, int64_t H, int64_t W, int C,
                      int64_t n_segments, double compactness, int max_iter, int convert2lab,
                      int enforce_connectivity, double min_size_factor, double max_size_factor,
@@ -401,6 +422,20 @@ int obia_oracle_slic(const float *image, const uint8_t *mask, int64_t H, int64_t
                      const double *seeds_yx, int64_t n_seeds, const double *seed_steps,
                      int64_t *labels, int64_t *labels_pre, float *centroids_out, int64_t *K_out)
 {
+    return obia_oracle_slic_sp(image, mask, H, W, C, n_segments, compactness, max_iter, convert2lab, enforce_connectivity, min_size_factor,
+                               max_size_factor, slic_zero, start_label, seeds_yx, n_seeds, seed_steps, labels, labels_pre, centroids_out,
+                               K_out, NULL);
+}
+/* spacing_yx (nullable = (1, 1)): slic()'s `spacing` for the row and column axes, cast to the image's float32 as
+ * `np.ascontiguousarray(spacing, dtype=dtype)` does (slic_superpixels.py) */
+int obia_oracle_slic_sp(const float *image, const uint8_t *mask, int64_t H, int64_t W, int C,
+                        int64_t n_segments, double compactness, int max_iter, int convert2lab,
+                        int enforce_connectivity, double min_size_factor, double max_size_factor,
+                        int slic_zero, int start_label,
+                        const double *seeds_yx, int64_t n_seeds, const double *seed_steps,
+                        int64_t *labels, int64_t *labels_pre, float *centroids_out, int64_t *K_out, const double *spacing_yx)
+{
+    const float sp_y = spacing_yx ? (float)spacing_yx[0] : 1.0f, sp_x = spacing_yx ? (float)spacing_yx[1] : 1.0f;
     if (start_label != 0 && start_label != 1) return OBIA_EINVAL;
     if (convert2lab == 1 && C != 3) return OBIA_EINVAL;
     const int64_t npix = H * W;
@@ -440,9 +475,9 @@ int obia_oracle_slic(const float *image, const uint8_t *mask, int64_t H, int64_t
 
     int rc = OBIA_OK;
     if (mask) /* step 2 of maskSLIC: spatial-only pre-pass updates `segments` in place */
-        rc = obia_oracle_slic_core(img, mask, segments, H, W, C, K, step, max_iter, slic_zero, 1, start_label, labels);
+        rc = obia_oracle_slic_core_sp(img, mask, segments, H, W, C, K, step, max_iter, slic_zero, 1, start_label, labels, sp_y, sp_x);
     if (rc == OBIA_OK)
-        rc = obia_oracle_slic_core(img, mask, segments, H, W, C, K, step, max_iter, slic_zero, 0, start_label, labels);
+        rc = obia_oracle_slic_core_sp(img, mask, segments, H, W, C, K, step, max_iter, slic_zero, 0, start_label, labels, sp_y, sp_x);
     if (rc == OBIA_OK && labels_pre) memcpy(labels_pre, labels, sizeof(int64_t) * (size_t)npix);
     if (rc == OBIA_OK && enforce_connectivity) {
         double segment_size;

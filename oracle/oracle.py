@@ -116,10 +116,16 @@ def _pairwise_sum(a):
 
 
 def gaussian_weights(sigma, truncate=4.0):
-    sd = float(sigma)
+    # slic() hands scipy its sigmas as float32 scalars (the image's dtype); scipy 1.7.1 with NumPy 1.26 (the goldens' versions)
+    # then forms `sigma2 = sigma * sigma` in FLOAT32 and everything after it in float64 (`sd = float(sigma)` for the radius,
+    # `-0.5 / sigma2` a Python float over a NumPy scalar).  (NumPy >= 2 keeps `-0.5 / sigma2` in float32 as well: the weights of a
+    # sigma whose square is not a float32 then differ from these by 1e-8 relative -- the smoothed image by an ulp here and there.)
+    s32 = np.float32(sigma)
+    sd = float(s32)
     lw = int(truncate * sd + 0.5)
+    sigma2 = float(np.float32(s32 * s32))
     x = np.arange(-lw, lw + 1)
-    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    phi = np.exp(-0.5 / sigma2 * x ** 2)
     return phi / _pairwise_sum(phi), lw
 
 
@@ -135,19 +141,23 @@ def _correlate1d_reflect(a, w, lw, axis):
     return np.moveaxis(tmp.astype(a.dtype), -1, axis)
 
 
-def sigma_zyx(sigma):
-    """slic()'s reading of its `sigma` argument with spacing = (1, 1, 1)."""
+def sigma_zyx(sigma, spacing=None):
+    """slic()'s reading of its `sigma` argument (slic_superpixels.py): the values live in the image's dtype (float32 here: 7.3 becomes
+    7.30000019...); a number is [s, s, s] DIVIDED by the spacing, a sequence is taken as (z, y, x) as it is."""
+    sp = np.ones(3, np.float32) if spacing is None else np.ascontiguousarray(spacing, dtype=np.float32)
     if np.isscalar(sigma):
-        return [float(sigma)] * 3
-    s = [float(v) for v in sigma]
-    if len(s) != 3:
-        raise ValueError("sigma: a number or a (z, y, x) sequence")
-    return s
+        s = np.array([sigma, sigma, sigma], dtype=np.float32)
+        s /= sp
+    else:
+        s = np.array(sigma, dtype=np.float32)
+        if s.shape != (3,):
+            raise ValueError("sigma: a number or a (z, y, x) sequence")
+    return [float(v) for v in s]
 
 
-def gaussian_filter_zyx(img_hwc, sigma):
+def gaussian_filter_zyx(img_hwc, sigma, spacing=None):
     out = np.ascontiguousarray(img_hwc, np.float32)[None]           # (1, H, W, C): the depth axis has one plane and is filtered too
-    for ax, s in enumerate(sigma_zyx(sigma)):
+    for ax, s in enumerate(sigma_zyx(sigma, spacing)):
         if s > 1e-15:
             w, lw = gaussian_weights(s)
             out = _correlate1d_reflect(out, w, lw, ax)
@@ -185,7 +195,7 @@ def enforce_connectivity(labels, min_size, max_size, start_label=1):
 
 def slic(image, n_segments=100, compactness=10.0, max_iter=10, convert2lab=None,
          enforce_connectivity=True, min_size_factor=0.5, max_size_factor=3, slic_zero=False,
-         start_label=1, mask=None, seeds_yx=None, seed_steps=None, return_all=False, sigma=0):
+         start_label=1, mask=None, seeds_yx=None, seed_steps=None, return_all=False, sigma=0, spacing=None):
     """skimage.segmentation.slic for a (H,W,C) float32 image (slic_superpixels.py:107-333).
 
     With ``mask`` and no ``seeds_yx`` the build's masked-grid seeding rule is used (see
@@ -199,11 +209,12 @@ def slic(image, n_segments=100, compactness=10.0, max_iter=10, convert2lab=None,
     if mask is not None:
         mask = np.ascontiguousarray(mask, np.uint8)
     c2l = -1 if convert2lab is None else int(bool(convert2lab))
-    if any(v > 0 for v in sigma_zyx(sigma)):   # smoothing sits between the Lab conversion and the scaling: Lab here, the rest in C
+    if any(v > 0 for v in sigma_zyx(sigma, spacing)):   # smoothing sits between the Lab conversion and the scaling: Lab here, the rest in C
         if C == 3 and c2l != 0:
             image = rgb2lab(image)
-        image = gaussian_filter_zyx(image, sigma)
+        image = gaussian_filter_zyx(image, sigma, spacing)
         c2l = 0
+    sp_yx = None if spacing is None else np.ascontiguousarray([float(np.float32(spacing[1])), float(np.float32(spacing[2]))], np.float64)
     labels = np.empty((H, W), np.int64)
     pre = np.empty((H, W), np.int64)
     if seeds_yx is not None:
@@ -218,13 +229,13 @@ def slic(image, n_segments=100, compactness=10.0, max_iter=10, convert2lab=None,
             kmax = max(1, masked_grid_centroids(mask, n_segments)[0].shape[0])
     cent = np.zeros((kmax, 2 + C), np.float32)
     K = _i64(0)
-    rc = lib().obia_oracle_slic(_ptr(image), _ptr(mask), _i64(H), _i64(W), ctypes.c_int(C), _i64(n_segments),
+    rc = lib().obia_oracle_slic_sp(_ptr(image), _ptr(mask), _i64(H), _i64(W), ctypes.c_int(C), _i64(n_segments),
                                 ctypes.c_double(compactness), ctypes.c_int(max_iter), ctypes.c_int(c2l),
                                 ctypes.c_int(bool(enforce_connectivity)), ctypes.c_double(min_size_factor),
                                 ctypes.c_double(max_size_factor), ctypes.c_int(bool(slic_zero)),
                                 ctypes.c_int(start_label), _ptr(seeds_yx),
                                 _i64(0 if seeds_yx is None else seeds_yx.shape[0]), _ptr(seed_steps),
-                                _ptr(labels), _ptr(pre), _ptr(cent), ctypes.byref(K))
+                                _ptr(labels), _ptr(pre), _ptr(cent), ctypes.byref(K), _ptr(sp_yx))
     if rc:
         raise ValueError(f"oracle slic rc={rc}")
     if return_all:

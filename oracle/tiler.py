@@ -22,7 +22,8 @@ HUGE = 0xFFFFFFFF
 
 class OracleTiler:
     def __init__(self, img, mask, Hg, row0, tile_size=200, buffer=30, crown_radius=5, pixel_size=(1.0, 1.0),
-                 n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5, max_size_factor=3, sigma=0):
+                 n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5, max_size_factor=3, sigma=0, spacing=None):
+        self.spacing = spacing
         self.sigma = sigma              # forwarded to slic() like every other keyword (tiling.py:137-143)
         self.img = np.asarray(img, np.float32)
         self.H, self.W, self.C = self.img.shape
@@ -59,7 +60,7 @@ class OracleTiler:
         if n < 1 or nvalid == 0:
             return
         lab = orc.slic(orc.normalize(tile), n_segments=int(n), compactness=self.compactness, max_iter=self.max_iter,
-                       mask=tmask.astype(np.uint8), min_size_factor=self.msf, max_size_factor=self.xsf, sigma=self.sigma)
+                       mask=tmask.astype(np.uint8), min_size_factor=self.msf, max_size_factor=self.xsf, sigma=self.sigma, spacing=self.spacing)
         sub = self.G[y0:y0 + h, x0:x0 + w]
         for l in np.unique(lab[lab > 0]):                      # labels are consecutive in first-pixel order
             sel = lab == l
@@ -119,13 +120,13 @@ class OracleTiler:
 
 
 def create_tiled_segments(img, mask=None, tile_size=200, buffer=30, crown_radius=5, pixel_size=(1.0, 1.0),
-                          n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5, max_size_factor=3, white_order=0, sigma=0):
+                          n_segments=None, compactness=10.0, max_iter=10, min_size_factor=0.5, max_size_factor=3, white_order=0, sigma=0, spacing=None):
     """white_order 0: the reference's raster order of white tiles; 1: even tile rows, then odd tile rows
     (the order of the sharded driver)."""
     img = np.asarray(img, np.float32)
     H = img.shape[0]
     t = OracleTiler(img, mask, H, 0, tile_size, buffer, crown_radius, pixel_size, n_segments, compactness, max_iter,
-                    min_size_factor, max_size_factor, sigma)
+                    min_size_factor, max_size_factor, sigma, spacing)
     nty = -(-H // tile_size)
     t.run(False, 0, nty)
     if white_order == 1:

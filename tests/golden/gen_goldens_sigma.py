@@ -22,11 +22,13 @@ from gen_goldens import obia_normalize, synth_dn  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def case(name, raw, params, sigma, mask=None):
+def case(name, raw, params, sigma, mask=None, spacing=None):
     raw_f32 = raw.astype(np.float32)
     img = obia_normalize(raw_f32)
     kw = dict(n_segments=params["n_segments"], compactness=params["compactness"], max_iter=10, sigma=sigma, multichannel=True,
               convert2lab=params.get("convert2lab", None), start_label=1)
+    if spacing is not None:
+        kw["spacing"] = list(spacing)
     seeds = {}
     if mask is not None:   # (maskSLIC is pinned on scikit-image's own seeds, as in gen_goldens.py)
         m3 = np.ascontiguousarray(mask[np.newaxis, ...], dtype=bool).view("uint8")
@@ -36,12 +38,19 @@ def case(name, raw, params, sigma, mask=None):
         kw["mask"] = mask
     pre = slic(img, enforce_connectivity=False, **kw)
     fin = slic(img, enforce_connectivity=True, **kw)
-    # the smoothed image as slic() forms it (scalar sigma -> [s, s, s] / spacing; a list is taken as (z, y, x))
-    sig = [float(sigma)] * 3 if np.isscalar(sigma) else [float(s) for s in sigma]
+    # the smoothed image as slic() forms it: sigma in the image's dtype (float32), a scalar divided by the spacing, a list taken as is
+    sp = np.ones(3, np.float32) if spacing is None else np.ascontiguousarray(spacing, dtype=np.float32)
+    if np.isscalar(sigma):
+        sg = np.array([sigma, sigma, sigma], dtype=np.float32)
+        sg /= sp
+    else:
+        sg = np.array(sigma, dtype=np.float32)
+    sig = [float(v) for v in sg]
     feat = rgb2lab(img) if (img.shape[2] == 3 and params.get("convert2lab", None) in (None, True)) else img
-    smooth = ndi.gaussian_filter(feat[np.newaxis].astype(np.float32), sig + [0])[0]
+    smooth = ndi.gaussian_filter(feat[np.newaxis].astype(np.float32), list(sg) + [0])[0] if (sg > 0).any() else feat
     out = dict(raw=raw, labels_pre=pre.astype(np.int32), labels=fin.astype(np.int32), smoothed=smooth.astype(np.float32),
-               sigma_zyx=np.asarray(sig, np.float64), params=np.array(repr(params)), skimage_version=np.array(skimage.__version__))
+               sigma_zyx=np.asarray(sig, np.float64), sigma_arg=np.asarray(sigma, np.float64),
+               spacing_zyx=np.asarray(sp, np.float64), params=np.array(repr(params)), skimage_version=np.array(skimage.__version__))
     if mask is not None:
         out["mask"] = mask.astype(np.uint8)
         out.update(seeds)
@@ -59,6 +68,11 @@ def main():
     mask = ((yy - 48) ** 2 + (xx - 64) ** 2 < 44 ** 2)
     mask[20:36, 50:70] = False
     case("sigma_mask_96x128x4", synth_dn(H, W, 4, seed=25), dict(n_segments=40, compactness=0.4), 1.5, mask=mask)
+    case("sigma_f32_70x80x4", synth_dn(70, 80, 4, seed=26), dict(n_segments=30, compactness=0.5), 7.3)      # 7.3 is not a float32: slic() rounds it
+    # spacing: anisotropic pixels (the row / column differences are scaled before they are squared; a scalar sigma is divided by it)
+    case("spacing_90x100x4", synth_dn(90, 100, 4, seed=27), dict(n_segments=45, compactness=0.6), 0, spacing=[1.0, 2.0, 0.5])
+    case("spacing_sigma_90x100x4", synth_dn(90, 100, 4, seed=28), dict(n_segments=45, compactness=0.6), 1.2, spacing=[3.0, 1.5, 0.75])
+    case("spacing_mask_96x128x4", synth_dn(H, W, 4, seed=29), dict(n_segments=40, compactness=0.4), 0, mask=mask, spacing=[1.0, 0.6, 1.7])
 
 
 if __name__ == "__main__":

@@ -41,8 +41,8 @@ def test_param_structs_match_header(lib):
     lib.load().obia_slic_default_params(ctypes.byref(p))
     assert (p.n_segments, p.compactness, p.max_num_iter, p.convert2lab, p.enforce_connectivity) == (100, 10.0, 10, -1, 1)
     assert (p.min_size_factor, p.max_size_factor, p.slic_zero, p.start_label, p.normalize_bands) == (0.5, 3.0, 0, 1, 0)
-    assert ctypes.sizeof(lib.SlicParams) == 3 * 8 + 10 * 4 + 3 * 8          # 3 doubles, 9 int32 + one reserved, sigma_zyx[3] (ABI 2)
-    assert p.exit_on_fixed_point == 0 and p.reserved == 0 and list(p.sigma_zyx) == [0.0, 0.0, 0.0]
+    assert ctypes.sizeof(lib.SlicParams) == 3 * 8 + 10 * 4 + 6 * 8          # 3 doubles, 9 int32 + one reserved, sigma_zyx[3], spacing_zyx[3] (ABI 2)
+    assert p.exit_on_fixed_point == 0 and p.reserved == 0 and list(p.sigma_zyx) == [0.0, 0.0, 0.0] and list(p.spacing_zyx) == [1.0, 1.0, 1.0]
     assert ctypes.sizeof(lib.TilingParams) == 3 * 8 + 4 * 4
 
 
@@ -67,8 +67,8 @@ def test_host_argument_checks_happen_before_device_use():
         slic(img, sigma=-2)            # (sigma >= 0 is supported since round 3: tests/test_gpu_sigma.py)
     with pytest.raises(ValueError):
         slic(img, sigma=[1, 2])
-    with pytest.raises(NotImplementedError):
-        slic(img, spacing=(1, 1, 1))
+    with pytest.raises(ValueError):
+        slic(img, spacing=(1, -1, 1))
     with pytest.raises(IndexError):
         create_segments(img, segmentation_bands=[7])
     with pytest.raises(Exception, match="unknown segmentation method"):

@@ -27,7 +27,7 @@ torch = pytest.importorskip("torch")
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_", "sigma")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_", "sigma", "spacing")))
 UNMASKED = [c for c in SLIC_CASES if not c.startswith("mask")]
 
 
@@ -355,8 +355,8 @@ def test_error_behaviour(amd):
         create_segments(img, segmentation_bands=[4], n_segments=4)
     with pytest.raises(Exception):
         create_segments(img, method="watershed")
-    with pytest.raises(NotImplementedError):
-        slic(img, spacing=[1.0, 2.0, 1.0])          # (sigma is implemented since round 3: tests/test_gpu_sigma.py)
+    with pytest.raises(ValueError):
+        slic(img, spacing=[1.0, -2.0, 1.0])         # (sigma and spacing are implemented since round 3: tests/test_gpu_sigma.py)
     with pytest.raises(ValueError):
         slic(img, sigma=-1.0)
 

@@ -13,7 +13,7 @@ from tests.metrics import adjusted_rand_index, label_disagreement
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "sigma*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "sigma*.npz")) + glob.glob(os.path.join(GOLD, "spacing*.npz")))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -22,8 +22,11 @@ def test_slic_with_sigma_vs_skimage_golden(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     params = ast.literal_eval(str(z["params"]))
     raw = torch.as_tensor(z["raw"].astype(np.float32)).cuda()
-    sig = [float(v) for v in z["sigma_zyx"]]
+    sig = float(z["sigma_arg"]) if z["sigma_arg"].shape == () else [float(v) for v in z["sigma_arg"]]   # as the caller wrote it
+    sp = [float(v) for v in z["spacing_zyx"]]
     kw = dict(n_segments=params["n_segments"], compactness=params["compactness"], sigma=sig, _normalize_bands=True)
+    if sp != [1.0, 1.0, 1.0]:
+        kw["spacing"] = sp
     if "mask" in z.files:
         kw.update(mask=z["mask"], seeds=(z["seeds_yx"], z["seed_steps_all"]))
     pre = slic(raw, enforce_connectivity=False, _stage="pre", **kw).cpu().numpy()
@@ -49,13 +52,37 @@ def test_scalar_sigma_is_the_same_width_on_every_axis(oracle):
     assert np.array_equal(a, b) and np.array_equal(a, ref)
 
 
-def test_negative_sigma_and_spacing_are_refused():
+def test_negative_sigma_and_bad_spacing_are_refused():
     from obia_amd.segmentation import slic
     img = torch.rand((32, 32, 4), device="cuda")
     with pytest.raises(ValueError):
         slic(img, n_segments=10, sigma=-1.0)
-    with pytest.raises(NotImplementedError):
-        slic(img, n_segments=10, spacing=[1, 2, 1])
+    with pytest.raises(ValueError):
+        slic(img, n_segments=10, spacing=[1, 0, 1])
+    with pytest.raises(ValueError):
+        slic(img, n_segments=10, spacing=[1, 2])
+
+
+def test_unit_spacing_is_the_default_path(oracle):
+    """spacing=(1, 1, 1) must not change a label (it is the default), and an anisotropic one must equal the oracle -- through the tiled
+    driver as well (every tile forwards it)."""
+    from obia_amd.segmentation import slic
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    rs = np.random.RandomState(4)
+    H, W = 200, 260
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.stack([np.sin(xx / (6 + c)) * np.cos(yy / (5 + c)) + 0.3 * rs.randn(H, W) for c in range(4)], -1).astype(np.float32)
+    a = slic(torch.as_tensor(img).cuda(), n_segments=150, compactness=0.4, _normalize_bands=True).cpu().numpy()
+    b = slic(torch.as_tensor(img).cuda(), n_segments=150, compactness=0.4, spacing=[1, 1, 1], _normalize_bands=True).cpu().numpy()
+    assert np.array_equal(a, b)
+    c = slic(torch.as_tensor(img).cuda(), n_segments=150, compactness=0.4, spacing=[1, 0.5, 1.75], sigma=0.8, _normalize_bands=True).cpu().numpy()
+    ref = oracle.slic(oracle.normalize(img), n_segments=150, compactness=0.4, spacing=[1, 0.5, 1.75], sigma=0.8)
+    assert np.array_equal(c, ref) and not np.array_equal(c, a)
+    kw = dict(tile_size=96, buffer=12, crown_radius=4, pixel_size=(0.5, 0.5), compactness=0.5, spacing=[1.0, 2.0, 0.7])
+    tref, n_ref = tiler.create_tiled_segments(img, None, **kw)
+    tl, n = create_tiled_segments(torch.as_tensor(img).cuda(), **kw)
+    assert n == n_ref and np.array_equal(tl.cpu().numpy(), tref)
 
 
 @pytest.mark.parametrize("sigma", [1.0, [0.0, 2.0, 0.6]])

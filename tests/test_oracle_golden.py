@@ -17,8 +17,8 @@ from tests.metrics import adjusted_rand_index, label_disagreement
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_", "sigma")))
-SIGMA_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "sigma*.npz")))
+                    if not os.path.basename(p).startswith(("connectivity_", "quickshift_", "moments_", "glcm_", "sigma", "spacing")))
+SIGMA_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "sigma*.npz")) + glob.glob(os.path.join(GOLD, "spacing*.npz")))
 
 
 def load(name):
@@ -57,19 +57,23 @@ def test_slic_labels_match_skimage(oracle, name):
 
 @pytest.mark.parametrize("name", SIGMA_CASES)
 def test_slic_with_sigma_matches_skimage(oracle, name):
-    """slic(..., sigma=...): the Gaussian pre-smoothing (scipy.ndimage.gaussian_filter between the Lab conversion and the scaling) --
-    the smoothed image bit for bit (Lab rasters: within the Lab tolerance), the labels as in the unsmoothed cases.
-    Fixtures: tests/golden/gen_goldens_sigma.py (scikit-image 0.18.3, SciPy 1.7.1)."""
+    """slic(..., sigma=..., spacing=...): the Gaussian pre-smoothing (scipy.ndimage.gaussian_filter between the Lab conversion and the
+    scaling; a scalar sigma divided by the spacing, everything in float32 as the image) and the anisotropic distance term -- the
+    smoothed image bit for bit (Lab rasters: within the Lab tolerance), the labels as in the other cases.
+    Fixtures: tests/golden/gen_goldens_sigma.py (scikit-image 0.18.3, SciPy 1.7.1, NumPy 1.26)."""
     z, params = load(name)
     img = oracle.normalize(z["raw"].astype(np.float32))
-    sig = [float(v) for v in z["sigma_zyx"]]
+    sig = float(z["sigma_arg"]) if z["sigma_arg"].shape == () else [float(v) for v in z["sigma_arg"]]
+    sp = [float(v) for v in z["spacing_zyx"]]
+    sp = None if sp == [1.0, 1.0, 1.0] else sp
+    assert oracle.sigma_zyx(sig, sp) == [float(v) for v in z["sigma_zyx"]]
     lab_case = z["raw"].shape[2] == 3 and params.get("convert2lab", None) is not False
-    sm = oracle.gaussian_filter_zyx(oracle.rgb2lab(img) if lab_case else img, sig)
+    sm = oracle.gaussian_filter_zyx(oracle.rgb2lab(img) if lab_case else img, sig, sp)
     if lab_case:
         assert np.abs(sm - z["smoothed"]).max() <= 2e-4
     else:
         assert np.array_equal(sm, z["smoothed"])
-    kw = dict(n_segments=params["n_segments"], compactness=params["compactness"], sigma=sig)
+    kw = dict(n_segments=params["n_segments"], compactness=params["compactness"], sigma=sig, spacing=sp)
     if "mask" in z.files:
         kw.update(mask=z["mask"], seeds_yx=z["seeds_yx"], seed_steps=z["seed_steps"])
     labels, pre, _ = oracle.slic(img, return_all=True, **kw)
