@@ -151,7 +151,33 @@ def cpu_baseline(C, tile, buffer_, crown_radius, pixel, compactness):
                             "sample": f"{T} such tiles in {T} processes at once, slowest {max(dts):.1f} s"}
     except Exception as e:   # the single-thread figure stands on its own
         out["all_cores"] = {"error": str(e)}
+    out["library"] = library_baseline(C, tile, n, compactness)
     return out
+
+
+def library_baseline(C, tile, n, compactness):
+    """scikit-image itself -- the library whose `slic` the reference's create_segments calls (segment_boundaries.py:48-51) -- on the
+    same tile, when an interpreter that has it is on the box (the build image's /opt/conda/bin/python3.9: scikit-image 0.18.3; the
+    bench's own interpreter has none).  Segmentation only and WITHOUT the mask: with one, scikit-image first seeds by k-means
+    (_get_mask_centroids) over a K x K distance matrix, minutes and gigabytes at this K.  A reported figure beside the port's, nothing
+    is derived from it."""
+    import subprocess
+    py = os.environ.get("OBIA_SKIMAGE_PYTHON", "/opt/conda/bin/python3.9")
+    if not os.path.exists(py):
+        return None
+    code = ("import time, warnings, numpy as np; warnings.filterwarnings('ignore'); import skimage; from skimage.segmentation import slic; "
+            "H = W = %d; C = %d; rs = np.random.RandomState(0); yy, xx = np.mgrid[0:H, 0:W].astype(np.float32); img = np.empty((H, W, C), np.float32)\n"
+            "for c in range(C):\n"
+            "    b = 400.0 * np.sin(xx / (11 + 3 * c)) * np.cos(yy / (13 + 2 * c)) + 1000 + 50 * c + rs.normal(0, 20, (H, W)); img[:, :, c] = (b - b.min()) / (b.max() - b.min())\n"
+            "t0 = time.time(); lab = slic(img, n_segments=%d, compactness=%r, max_iter=10, sigma=0, multichannel=True, convert2lab=False, start_label=1); "
+            "print(skimage.__version__, time.time() - t0, len(np.unique(lab)))") % (tile, C, n, compactness)
+    try:
+        r = subprocess.run([py, "-c", code], capture_output=True, text=True, timeout=180)
+        ver, dt, nseg = r.stdout.strip().splitlines()[-1].split()
+        return {"value": tile * tile / float(dt) / 1e6, "unit": "Mpixel/s", "cores": 1, "what": f"skimage.segmentation.slic {ver}",
+                "sample": f"one {tile}x{tile}x{C} tile, n_segments={n}, no mask, segmentation only (normalised bands in, labels out): {float(dt):.1f} s, {nseg} segments"}
+    except Exception as e:
+        return {"error": str(e)[:200]}
 
 
 def main():
