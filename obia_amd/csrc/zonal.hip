@@ -16,7 +16,7 @@ namespace obia {
 #define ZR 2
 #endif
 #ifndef ZTW
-#define ZTW 128   /* columns of a zonal_kernel tile (the moments kernel keeps Z_TILE x Z_TILE) */
+#define ZTW 128   /* columns of a tile (ZTH rows) */
 #endif
 #ifndef ZTH
 #define ZTH 64
@@ -24,13 +24,11 @@ namespace obia {
 #ifndef ZSLOTS
 #define ZSLOTS 64
 #endif
-constexpr int Z_TILE = 64, Z_SLOTS = 64, Z_MAXB = 16, Z_ROWS = ZR;
+constexpr int Z_MAXB = 16, Z_ROWS = ZR;
 
 struct BandList { int n; int identity; int b[Z_MAXB]; };   // identity: b[i] == i for every i < n
-// four consecutive bands of one pixel: 16 bytes at a 4-byte aligned address when the band count is not a multiple of four (the
-// author's rasters have nine) -- gfx950 loads a dwordx4 from any dword address, the type only tells the compiler so
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
-
+// (the bands of a lane: 16 or 12 bytes at a 4-byte aligned address -- gfx950 loads a dwordx4 / dwordx3 from any dword address, the
+// `aligned(4)` of the vector types only tells the compiler so)
 typedef float z_v4f __attribute__((ext_vector_type(4), aligned(4)));
 typedef float z_v3f __attribute__((ext_vector_type(3), aligned(4)));
 // the BPL consecutive bands of a lane: ONE nontemporal load (the raster is read once) of 16 or 12 bytes at dword alignment
@@ -294,31 +292,39 @@ __global__ void zonal_finalize_kernel(const unsigned *__restrict__ g_cnt, const 
 //   NaN where m2 <= (eps * mean)^2 (scipy >= 1.9: "nearly constant" data), eps = float32 epsilon (the raster dtype).
 // Second pass of the same shape as zonal_kernel: the per-label means of the first pass are the pivots, so the power
 // sums are CENTRAL (no cancellation); a lane loads the four means of its band quad once per run.
-template <int NBP>
-__global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_moments_kernel(
+// (row loop as in zonal_kernel: uniform row pointers + fixed lane offsets, clamped columns / rows, raster read whatever the label,
+// no per-band branches -- a NaN contributes a zero difference and no count.  MODE 0: all band quads full and in order; 1: in order
+// with a partial last quad; 2: gathered subset.)
+template <int NBP, int MODE>
+__global__ __launch_bounds__(ZTW / 4 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW))) void zonal_moments_kernel(
     const float *__restrict__ raw, const int32_t *__restrict__ labels, int H, int W, int C, BandList bl, int n_labels,
     int start_label, const double *__restrict__ mean, unsigned *__restrict__ g_n, double *__restrict__ g_s2,
     double *__restrict__ g_s3, double *__restrict__ g_s4) {
-    constexpr int LPP = NBP / 4, NT = 64 * LPP;
-    __shared__ int s_key[Z_SLOTS];
-    __shared__ unsigned s_n[Z_SLOTS][NBP];
-    __shared__ double s_s2[Z_SLOTS][NBP], s_s3[Z_SLOTS][NBP], s_s4[Z_SLOTS][NBP];
+    constexpr int LPP = NBP / 4, NT = ZTW * LPP;
+    __shared__ int s_key[ZSLOTS];
+    __shared__ unsigned s_n[ZSLOTS][NBP];
+    __shared__ double s_s2[ZSLOTS][NBP], s_s3[ZSLOTS][NBP], s_s4[ZSLOTS][NBP];
     const int tid = threadIdx.x;
     const int nb = bl.n;
-    for (int i = tid; i < Z_SLOTS; i += NT) s_key[i] = -1;
-    for (int i = tid; i < Z_SLOTS * NBP; i += NT) {
+    for (int i = tid; i < ZSLOTS; i += NT) s_key[i] = -1;
+    for (int i = tid; i < ZSLOTS * NBP; i += NT) {
         (&s_n[0][0])[i] = 0u; (&s_s2[0][0])[i] = 0.0; (&s_s3[0][0])[i] = 0.0; (&s_s4[0][0])[i] = 0.0;
     }
     __syncthreads();
-    const int tiles_x = (W + Z_TILE - 1) / Z_TILE;
-    const int ty0 = (blockIdx.x / tiles_x) * Z_TILE, tx0 = (blockIdx.x % tiles_x) * Z_TILE;
+    const int tiles_x = (W + ZTW - 1) / ZTW;
+    const int ty0 = (blockIdx.x / tiles_x) * ZTH, tx0 = (blockIdx.x % tiles_x) * ZTW;
     const int x = tx0 + tid / LPP, q = tid % LPP;
     const int nbq = min(4, max(0, nb - 4 * q));
-    const bool vec = (nb == C) && bl.identity && nbq == 4;
     const bool col_ok = x < W;
-    int bsel[4];
+    const int xc = col_ok ? x : W - 1;
+    const unsigned loff = (unsigned)xc * 4u;
+    unsigned roff[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bsel[b] = (q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b];
+    for (int b = 0; b < 4; ++b) {
+        const int band = MODE < 2 ? 4 * q + b : ((q == 0) ? bl.b[b] : (q == 1) ? bl.b[4 + b] : (q == 2) ? bl.b[8 + b] : bl.b[12 + b]);
+        roff[b] = ((unsigned)xc * (unsigned)C + (unsigned)(b < nbq ? band : 0)) * 4u;
+    }
+    const bool full = MODE == 0 || (MODE == 1 && nbq == 4);
 
     int rl = -1;
     unsigned rn[4];
@@ -327,23 +333,26 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
     for (int b = 0; b < 4; ++b) { rn[b] = 0; mu[b] = 0.0; r2[b] = 0.0; r3[b] = 0.0; r4[b] = 0.0; }
     auto close_run = [&]() {
         if (rl < 0) return;
-        const unsigned h = ((unsigned)rl * 2654435761u) >> 26;
+        const unsigned h = ((unsigned)rl * 2654435761u) >> 16;
         int slot = -1;
 #pragma unroll 1
-        for (int probe = 0; probe < Z_SLOTS; ++probe) {
-            const int sidx = (h + probe) & (Z_SLOTS - 1);
+        for (int probe = 0; probe < ZSLOTS; ++probe) {
+            const int sidx = (h + probe) % ZSLOTS;
             const int old = atomicCAS(&s_key[sidx], -1, rl);
             if (old == -1 || old == rl) { slot = sidx; break; }
         }
+        if (slot >= 0) {   // no conditions: an empty band adds zeros, a padded band slot collects zeros nobody reads
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= nbq || rn[b] == 0) continue;
-            if (slot >= 0) {
+            for (int b = 0; b < 4; ++b) {
                 atomicAdd(&s_n[slot][4 * q + b], rn[b]);
                 atomicAdd(&s_s2[slot][4 * q + b], r2[b]);
                 atomicAdd(&s_s3[slot][4 * q + b], r3[b]);
                 atomicAdd(&s_s4[slot][4 * q + b], r4[b]);
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b >= nbq || rn[b] == 0) continue;
                 const size_t o = (size_t)rl * nb + 4 * q + b;
                 atomicAdd(&g_n[o], rn[b]);
                 unsafeAtomicAdd(&g_s2[o], r2[b]);
@@ -353,43 +362,42 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
         }
     };
     int lab[2][Z_ROWS];
-    float4 val[2][Z_ROWS];
-    auto fetch = [&](int buf, int y0) {
+    float val[2][Z_ROWS][4];
+    const size_t row_bytes = (size_t)W * C * 4, lab_bytes = (size_t)W * 4;
+    const char *lrow = reinterpret_cast<const char *>(labels) + (size_t)ty0 * lab_bytes;
+    const char *rrow = reinterpret_cast<const char *>(raw) + (size_t)ty0 * row_bytes;
+    int y_next = ty0;
+    auto fetch = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < Z_ROWS; ++j) {
-            const int y = y0 + j;
-            int l = -1;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (col_ok && y < H) {
-                const long long pix = (long long)y * W + x;
-                l = labels[pix] - start_label;
-                if (l < 0 || l >= n_labels) l = -1;
-                if (l >= 0 && nbq > 0) {
-                    const float *px = raw + pix * C;
-                    if (vec) { const f4u t = *reinterpret_cast<const f4u *>(px + 4 * q); v = make_float4(t.x, t.y, t.z, t.w); }
-                    else {
-                        v.x = px[bsel[0]];
-                        if (nbq > 1) v.y = px[bsel[1]];
-                        if (nbq > 2) v.z = px[bsel[2]];
-                        if (nbq > 3) v.w = px[bsel[3]];
-                    }
-                }
+            int l = *reinterpret_cast<const int *>(lrow + loff) - start_label;
+            if ((unsigned)l >= (unsigned)n_labels || !col_ok || y_next >= H) l = -1;
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (full) ld_raster<4>(reinterpret_cast<const float *>(rrow + roff[0]), v);
+            else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (b < nbq) v[b] = *reinterpret_cast<const float *>(rrow + roff[b]);
             }
-            lab[buf][j] = l; val[buf][j] = v;
+            lab[buf][j] = l;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) val[buf][j][b] = v[b];
+            ++y_next;
+            if (y_next < H) { lrow += lab_bytes; rrow += row_bytes; }
         }
     };
-    const int y_end = min(ty0 + Z_TILE, H);
-    fetch(0, ty0);
+    constexpr int NG = ZTH / Z_ROWS;
+    const int y_end = min(ty0 + ZTH, H);
+    fetch(0);
 #pragma unroll 1
-    for (int g = 0; g < Z_TILE / Z_ROWS; g += 2) {
+    for (int g = 0; g < NG; g += 2) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int y0 = ty0 + (g + half) * Z_ROWS;
             if (y0 >= y_end) break;
-            fetch(half ^ 1, y0 + Z_ROWS);
+            if (g + half + 1 < NG) fetch(half ^ 1);
 #pragma unroll
             for (int j = 0; j < Z_ROWS; ++j) {
-                const int l = (y0 + j < y_end) ? lab[half][j] : -1;
+                const int l = lab[half][j];
                 if (l != rl) {
                     close_run();
                     rl = l;
@@ -400,20 +408,20 @@ __global__ __launch_bounds__(16 * NBP) __attribute__((amdgpu_waves_per_eu(ZW, ZW
                     }
                 }
                 if (l < 0) continue;
-                const float v[4] = {val[half][j].x, val[half][j].y, val[half][j].z, val[half][j].w};
+                const float *v = val[half][j];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    if (b >= nbq || !(v[b] == v[b])) continue;   // NaN pixels are dropped per band
-                    const double d = (double)v[b] - mu[b];
+                    const bool ok = v[b] == v[b];                 // NaN pixels are dropped per band: no count, a zero difference
+                    const double d = ok ? (double)v[b] - mu[b] : 0.0;
                     const double d2 = d * d;
-                    rn[b] += 1; r2[b] += d2; r3[b] += d2 * d; r4[b] += d2 * d2;
+                    rn[b] += ok ? 1u : 0u; r2[b] += d2; r3[b] = fma(d2, d, r3[b]); r4[b] = fma(d2, d2, r4[b]);
                 }
             }
         }
     }
     close_run();
     __syncthreads();
-    for (int i = tid; i < Z_SLOTS * nb; i += NT) {
+    for (int i = tid; i < ZSLOTS * nb; i += NT) {
         const int slot = i / nb, b = i - slot * nb;
         const int l = s_key[slot];
         if (l < 0 || s_n[slot][b] == 0) continue;
@@ -475,15 +483,24 @@ int zonal_moments_dev(obia_ctx *ctx, const float *raw, const int32_t *labels, in
     OBIA_HIP_TRY(hipMemsetAsync(g_s2, 0, sizeof(double) * nlb, ctx->stream));
     OBIA_HIP_TRY(hipMemsetAsync(g_s3, 0, sizeof(double) * nlb, ctx->stream));
     OBIA_HIP_TRY(hipMemsetAsync(g_s4, 0, sizeof(double) * nlb, ctx->stream));
-    const int tiles = cdiv(W, Z_TILE) * cdiv(H, Z_TILE);
-#define LAUNCH_ZM(NBPV)                                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_moments_kernel<NBPV>), dim3(tiles), dim3(16 * NBPV), 0, ctx->stream, raw, \
+    if ((long long)W * C * 4 >= (1ll << 32)) { set_error("a raster row of %lld bytes is not supported (4 GB at most)", (long long)W * C * 4); return OBIA_E_UNSUPPORTED; }
+    const int tiles = cdiv(W, ZTW) * cdiv(H, ZTH);
+    const bool ident = bl.identity && bl.n == C;
+#define LAUNCH_ZM_MODE(NBPV, MODEV)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zonal_moments_kernel<NBPV, MODEV>), dim3(tiles), dim3(ZTW / 4 * NBPV), 0, ctx->stream, raw, \
                        labels, H, W, C, bl, n_labels, start_label, mean, g_n, g_s2, g_s3, g_s4)
+#define LAUNCH_ZM(NBPV)                                                                                              \
+    do {                                                                                                             \
+        if (ident && bl.n == NBPV) LAUNCH_ZM_MODE(NBPV, 0);                                                          \
+        else if (ident) LAUNCH_ZM_MODE(NBPV, 1);                                                                     \
+        else LAUNCH_ZM_MODE(NBPV, 2);                                                                                \
+    } while (0)
     if (bl.n <= 4) LAUNCH_ZM(4);
     else if (bl.n <= 8) LAUNCH_ZM(8);
     else if (bl.n <= 12) LAUNCH_ZM(12);
     else LAUNCH_ZM(16);
 #undef LAUNCH_ZM
+#undef LAUNCH_ZM_MODE
     int ib = cdiv((long long)nlb, 256);
     if (ib > 4096) ib = 4096;
     hipLaunchKernelGGL(zonal_moments_finalize_kernel, dim3(ib), dim3(256), 0, ctx->stream, g_n, g_s2, g_s3, g_s4, mean,
