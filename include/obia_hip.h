@@ -208,12 +208,14 @@ int obia_texture_stats_f32_dev(obia_ctx *ctx, const float *raw_hwc, const int32_
  * noise scikit-image adds to the densities, RandomState(random_seed).normal(scale=1e-5) -- generated by the host
  * (NumPy's legacy stream is stable); NULL = no noise.  labels_out: consecutive ids from 0 in ascending order of the
  * root pixel (np.unique(...)[1]).  Up to 16 bands, any kernel_size >= 1 (1 / 3 / 4 bands with kernel_size <= 5 -- the
- * reference's usual calls -- take the LDS-staged kernel, everything else the same arithmetic on global memory).           */
+ * reference's usual calls -- take the LDS-staged kernel, everything else the same arithmetic on global memory).
+ * sigma (ABI 2): scikit-image's Gaussian pre-smoothing, `ndi.gaussian_filter(image, [sigma, sigma, 0])` on the float64 image after
+ * the Lab conversion and before `* ratio`; 0 = none.                                                                        */
 int obia_quickshift_f32(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
-                        double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                        double max_dist, double sigma, int convert2lab, const double *tie_noise_hw, int normalize_bands,
                         int32_t *labels_out, int *n_labels_out);
 int obia_quickshift_f32_dev(obia_ctx *ctx, const float *img_hwc, int H, int W, int C, double ratio, double kernel_size,
-                            double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                            double max_dist, double sigma, int convert2lab, const double *tie_noise_hw, int normalize_bands,
                             int32_t *labels_out, int *n_labels_out);
 
 /* ---- B3: tiled driver ------------------------------------------------------------------------------

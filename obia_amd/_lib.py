@@ -66,8 +66,8 @@ _SIGNATURES = {
     "obia_sample_labels_i32_dev": (_I, [_P, _P, _I, _I, _P, _P, ctypes.c_int64, _I, _P]),
     "obia_polygon_count_i32_dev": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "obia_polygon_rings_i32_dev": (_I, [_P, _P, _I, _I, _I, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P, _P, _P]),
-    "obia_quickshift_f32": (_I, [_P, _P, _I, _I, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _I, _P, ctypes.POINTER(_I)]),
-    "obia_quickshift_f32_dev": (_I, [_P, _P, _I, _I, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _I, _P, ctypes.POINTER(_I)]),
+    "obia_quickshift_f32": (_I, [_P, _P, _I, _I, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _I, _P, ctypes.POINTER(_I)]),
+    "obia_quickshift_f32_dev": (_I, [_P, _P, _I, _I, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _I, _P, ctypes.POINTER(_I)]),
     "obia_tiled_slic_f32_dev": (_I, [_P, _P, _P, _I, _I, _I, ctypes.POINTER(TilingParams), ctypes.POINTER(SlicParams), _P,
                                      ctypes.POINTER(ctypes.c_int64)]),
     "obia_tiled_slic_f32": (_I, [_P, _P, _P, _I, _I, _I, ctypes.POINTER(TilingParams), ctypes.POINTER(SlicParams), _P,

@@ -60,6 +60,29 @@ __global__ __launch_bounds__(256) void qs_prepare_kernel(const float *__restrict
     }
 }
 
+// Gaussian pre-smoothing (`ndi.gaussian_filter(image, [sigma, sigma, 0])` on the float64 image): one axis pass of scipy's correlate1d
+// (symmetric weights, mode 'reflect', see gauss_axis_kernel in slic.hip) over the channel planes [C][H][W]; `scale` multiplies the
+// output (the last pass applies `* ratio`: the filter's own result is a double, so the product rounds as `image * ratio` does).
+__global__ __launch_bounds__(256) void qs_gauss_axis_kernel(const double *__restrict__ in, double *__restrict__ out, int H, int W,
+                                                            long long n_el, int axis_y, const double *__restrict__ w, int r, double scale) {
+    const long long plane = (long long)H * W;
+    const int n = axis_y ? H : W;
+    const long long stride = axis_y ? W : 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+        const long long in_plane = i % plane;
+        const int pos = axis_y ? (int)(in_plane / W) : (int)(in_plane % W);
+        const double *line = in + (i - (long long)pos * stride);
+        double tmp = in[i] * w[0];
+        for (int j = r; j >= 1; --j) {
+            const int per = 2 * n;
+            int lo = (pos - j) % per; if (lo < 0) lo += per; if (lo >= n) lo = per - 1 - lo;
+            int hi = (pos + j) % per; if (hi >= n) hi = per - 1 - hi;
+            tmp += (line[(long long)lo * stride] + line[(long long)hi * stride]) * w[j];
+        }
+        out[i] = tmp * scale;
+    }
+}
+
 // P1 (density) and P2 (parent) share the staged neighbourhood.
 template <int C>
 __global__ __launch_bounds__(QT * QT) void qs_density_parent_kernel(const double *__restrict__ img, const double *__restrict__ noise,
@@ -257,13 +280,14 @@ __global__ void qs_labels_kernel(const int *__restrict__ parent, const int *__re
 }
 
 static int quickshift_dev(obia_ctx *ctx, const float *img, int H, int W, int C, double ratio, double kernel_size, double max_dist,
-                          int convert2lab, const double *noise, int normalize_bands, int32_t *labels_out, int *n_labels_out) {
+                          double sigma, int convert2lab, const double *noise, int normalize_bands, int32_t *labels_out, int *n_labels_out) {
     if (!img || !labels_out || H <= 0 || W <= 0 || C <= 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
     if ((long long)H * W > 0x7fffffffLL) { set_error("raster above 2^31 pixels"); return OBIA_E_INVALID; }
     if (!(kernel_size >= 1.0)) { set_error("`kernel_size` should be >= 1."); return OBIA_E_INVALID; }
     if (convert2lab && C != 3) { set_error("Only RGB images can be converted to Lab space."); return OBIA_E_INVALID; }
     if (C > QC_MAX) { set_error("quickshift: more than %d bands not supported (got %d)", QC_MAX, C); return OBIA_E_UNSUPPORTED; }
     if (!(kernel_size < 1.0e4)) { set_error("`kernel_size` too large"); return OBIA_E_INVALID; }
+    if (!(sigma >= 0.0) || !(sigma < 1.0e6)) { set_error("sigma must be >= 0"); return OBIA_E_INVALID; }
     const int kw = (int)std::ceil(3.0 * kernel_size);
     // the LDS-staged kernel covers the reference's usual calls (1, 3 or 4 bands, kernel_size <= 5); everything else runs the
     // same arithmetic on global memory
@@ -289,7 +313,19 @@ static int quickshift_dev(obia_ctx *ctx, const float *img, int H, int W, int C, 
     OBIA_TRY(slic_prepare_features(ctx, b, img, H, W, normalize_bands, 0, 1.0f));
     int gs = cdiv(n, 256 * 4);
     if (gs > 65535) gs = 65535;
-    hipLaunchKernelGGL(qs_prepare_kernel, dim3(gs), dim3(256), 0, ctx->stream, b.d_feat, b.CP, C, n, convert2lab ? 1 : 0, ratio, d_img);
+    const bool smoothing = sigma > 1e-15;
+    hipLaunchKernelGGL(qs_prepare_kernel, dim3(gs), dim3(256), 0, ctx->stream, b.d_feat, b.CP, C, n, convert2lab ? 1 : 0, smoothing ? 1.0 : ratio, d_img);
+    if (smoothing) {   // rows, then columns (gaussian_filter walks the axes in order; the band axis has sigma 0), then `* ratio`
+        std::vector<double> w;
+        const int r = gaussian_weights_host(sigma, false, w);
+        double *d_w = A.get<double>(w.size()), *d_tmp = A.get<double>((size_t)n * C);
+        if (!d_w || !d_tmp) return OBIA_E_NOMEM;
+        OBIA_TRY(upload_async(ctx, d_w, w.data(), sizeof(double) * w.size()));
+        int gg = cdiv(n * C, 256);
+        if (gg > 65535) gg = 65535;
+        hipLaunchKernelGGL(qs_gauss_axis_kernel, dim3(gg), dim3(256), 0, ctx->stream, d_img, d_tmp, H, W, n * C, 1, d_w, r, 1.0);
+        hipLaunchKernelGGL(qs_gauss_axis_kernel, dim3(gg), dim3(256), 0, ctx->stream, d_tmp, d_img, H, W, n * C, 0, d_w, r, ratio);
+    }
     // 2. density, 3. parent
     const double inv = -0.5 / (kernel_size * kernel_size);
     const int side = QT + 2 * kw;
@@ -341,7 +377,7 @@ using namespace obia;
 extern "C" {
 
 int obia_quickshift_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C, double ratio, double kernel_size,
-                            double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                            double max_dist, double sigma, int convert2lab, const double *tie_noise_hw, int normalize_bands,
                             int32_t *labels_out, int *n_labels_out) {
     if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
     if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
@@ -350,7 +386,7 @@ int obia_quickshift_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C
     int rc;
     {
         ScopedSpan total(ctx, T_TOTAL);
-        rc = quickshift_dev(ctx, img, H, W, C, ratio, kernel_size, max_dist, convert2lab, tie_noise_hw, normalize_bands,
+        rc = quickshift_dev(ctx, img, H, W, C, ratio, kernel_size, max_dist, sigma, convert2lab, tie_noise_hw, normalize_bands,
                             labels_out, n_labels_out);
     }
     if (rc != OBIA_OK) return rc;
@@ -360,7 +396,7 @@ int obia_quickshift_f32_dev(obia_ctx *ctx, const float *img, int H, int W, int C
 }
 
 int obia_quickshift_f32(obia_ctx *ctx, const float *img, int H, int W, int C, double ratio, double kernel_size,
-                        double max_dist, int convert2lab, const double *tie_noise_hw, int normalize_bands,
+                        double max_dist, double sigma, int convert2lab, const double *tie_noise_hw, int normalize_bands,
                         int32_t *labels_out, int *n_labels_out) {
     if (!ctx) { set_error("null context"); return OBIA_E_INVALID; }
     if (!img || !labels_out || H <= 0 || W <= 0 || C <= 0) { set_error("bad arguments"); return OBIA_E_INVALID; }
@@ -376,7 +412,7 @@ int obia_quickshift_f32(obia_ctx *ctx, const float *img, int H, int W, int C, do
     if (rc == OBIA_OK && hipMemcpyAsync(d_img, img, npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
     if (rc == OBIA_OK && tie_noise_hw && hipMemcpyAsync(d_noise, tie_noise_hw, npix * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = OBIA_E_HIP;
     if (rc == OBIA_E_HIP) set_error("host->device copy failed in obia_quickshift_f32");
-    if (rc == OBIA_OK) rc = obia_quickshift_f32_dev(ctx, d_img, H, W, C, ratio, kernel_size, max_dist, convert2lab, d_noise, normalize_bands, d_lab, n_labels_out);
+    if (rc == OBIA_OK) rc = obia_quickshift_f32_dev(ctx, d_img, H, W, C, ratio, kernel_size, max_dist, sigma, convert2lab, d_noise, normalize_bands, d_lab, n_labels_out);
     if (rc == OBIA_OK && hipMemcpyAsync(labels_out, d_lab, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
         set_error("device->host copy failed in obia_quickshift_f32");
         rc = OBIA_E_HIP;

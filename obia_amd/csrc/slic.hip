@@ -418,7 +418,23 @@ static double np_pairwise_sum(const double *a, size_t n) {
     return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
 
-// scratch arrays and the three weight tables (scipy _gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), x = -r..r, r = int(4 sigma + 0.5))
+// scipy _gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), x = -r..r, r = int(4 sigma + 0.5), divided by the NumPy sum; w[0] = centre.
+// sigma_is_f32: slic() hands scipy a float32 scalar (the image's dtype) and scipy squares it in float32 before everything else runs in
+// double; quickshift() hands it the caller's Python number.
+int gaussian_weights_host(double sigma, bool sigma_is_f32, std::vector<double> &w) {
+    const float s32 = (float)sigma;
+    const double sd = sigma_is_f32 ? (double)s32 : sigma;
+    const int r = (int)(4.0 * sd + 0.5);
+    const double sigma2 = sigma_is_f32 ? (double)(s32 * s32) : sigma * sigma;
+    std::vector<double> phi((size_t)2 * r + 1);
+    for (int x = -r; x <= r; ++x) phi[(size_t)(x + r)] = std::exp(-0.5 / sigma2 * (double)((long long)x * x));
+    const double sum = np_pairwise_sum(phi.data(), phi.size());
+    w.resize((size_t)r + 1);
+    for (int j = 0; j <= r; ++j) w[(size_t)j] = phi[(size_t)(r + j)] / sum;
+    return r;
+}
+
+// scratch arrays and the three weight tables
 int smooth_prepare(obia_ctx *ctx, SmoothSpec &sm, long long total_pix, long long maxpix, int CP, int np) {
     if (!sm.on()) return OBIA_OK;
     Arena &A = ctx->arena;
@@ -430,16 +446,8 @@ int smooth_prepare(obia_ctx *ctx, SmoothSpec &sm, long long total_pix, long long
     for (int ax = 0; ax < 3; ++ax) {
         if (!(sm.sigma[ax] > 1e-15)) continue;
         if (!(sm.sigma[ax] < 1.0e6)) { set_error("sigma %g not supported", sm.sigma[ax]); return OBIA_E_INVALID; }
-        // the sigma slic() hands scipy is a float32 (the image's dtype); scipy forms sigma * sigma in float32, the rest in double
-        const float s32 = (float)sm.sigma[ax];
-        const double sd = (double)s32;
-        const int r = (int)(4.0 * sd + 0.5);
-        const double sigma2 = (double)(s32 * s32);
-        std::vector<double> phi((size_t)2 * r + 1);
-        for (int x = -r; x <= r; ++x) phi[(size_t)(x + r)] = std::exp(-0.5 / sigma2 * (double)((long long)x * x));
-        const double sum = np_pairwise_sum(phi.data(), phi.size());
-        std::vector<double> w((size_t)r + 1);
-        for (int j = 0; j <= r; ++j) w[(size_t)j] = phi[(size_t)(r + j)] / sum;
+        std::vector<double> w;
+        const int r = gaussian_weights_host(sm.sigma[ax], true, w);
         sm.radius[ax] = r;
         sm.d_w[ax] = A.get<double>((size_t)r + 1);
         if (!sm.d_w[ax]) return OBIA_E_NOMEM;

@@ -123,6 +123,7 @@ struct SmoothSpec {
     bool on() const { return sigma[0] > 1e-15 || sigma[1] > 1e-15 || sigma[2] > 1e-15; }
 };
 int smooth_prepare(obia_ctx *ctx, SmoothSpec &sm, long long total_pix, long long maxpix, int CP, int np);
+int gaussian_weights_host(double sigma, bool sigma_is_f32, std::vector<double> &w);   // returns the radius; w[0] = centre weight
 int slic_features_launch(hipStream_t stream, int C, int CP, int np, const SrcWindow *d_windows, int maxh, const float *src, int Ws,
                          int normalize, int to_lab, float ratio, float *d_feat, unsigned *d_keys, bool planes = true,
                          float *d_fbox = nullptr,    // d_fbox (plane layout only): the footprints' colour boxes from the same pass

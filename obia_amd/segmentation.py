@@ -194,8 +194,8 @@ def quickshift(image, ratio=1.0, kernel_size=5, max_dist=10, return_tree=False, 
     """
     if return_tree:
         raise NotImplementedError("return_tree=True is not implemented")
-    if np.any(np.asarray(sigma) != 0):
-        raise NotImplementedError("sigma != 0 (Gaussian pre-smoothing) is not implemented; obia never sets it")
+    if not np.isscalar(sigma) or not (float(sigma) >= 0.0):
+        raise ValueError("sigma: a number >= 0 (the width of the Gaussian pre-smoothing on both raster axes)")
     if channel_axis not in (-1, None, 2):
         raise NotImplementedError("channel_axis must be -1")
     if kernel_size < 1:
@@ -235,7 +235,7 @@ def quickshift(image, ratio=1.0, kernel_size=5, max_dist=10, return_tree=False, 
         out = torch.empty((H, W), dtype=torch.int32, device=img.device)
         torch.cuda.current_stream(dev).synchronize()
         _lib.check(lib.obia_quickshift_f32_dev(c.handle, img.data_ptr(), H, W, C, float(ratio), float(kernel_size),
-                                               float(max_dist), int(bool(convert2lab)), nz.data_ptr(),
+                                               float(max_dist), float(sigma), int(bool(convert2lab)), nz.data_ptr(),
                                                int(bool(_normalize_bands)), out.data_ptr(), ctypes.byref(n_out)))
         return out
     img = np.asarray(image)
@@ -245,7 +245,7 @@ def quickshift(image, ratio=1.0, kernel_size=5, max_dist=10, return_tree=False, 
     c = ctx or _lib.default_context(0)
     out = np.empty((H, W), np.int32)
     _lib.check(lib.obia_quickshift_f32(c.handle, _lib.np_ptr(img), H, W, C, float(ratio), float(kernel_size), float(max_dist),
-                                       int(bool(convert2lab)), _lib.np_ptr(noise), int(bool(_normalize_bands)),
+                                       float(sigma), int(bool(convert2lab)), _lib.np_ptr(noise), int(bool(_normalize_bands)),
                                        _lib.np_ptr(out), ctypes.byref(n_out)))
     return out.astype(np.int64)
 

@@ -115,6 +115,15 @@ def _pairwise_sum(a):
     return _pairwise_sum(a[:n2]) + _pairwise_sum(a[n2:])
 
 
+def gaussian_weights_f64(sigma, truncate=4.0):
+    """quickshift() hands scipy the caller's Python number: everything in float64 (scipy _gaussian_kernel1d)."""
+    sd = float(sigma)
+    lw = int(truncate * sd + 0.5)
+    x = np.arange(-lw, lw + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return phi / _pairwise_sum(phi), lw
+
+
 def gaussian_weights(sigma, truncate=4.0):
     # slic() hands scipy its sigmas as float32 scalars (the image's dtype); scipy 1.7.1 with NumPy 1.26 (the goldens' versions)
     # then forms `sigma2 = sigma * sigma` in FLOAT32 and everything after it in float64 (`sd = float(sigma)` for the radius,
@@ -322,6 +331,17 @@ def zonal_stats_c(raw, labels, bands=None, start_label=1, n_labels=None):
     if rc:
         raise RuntimeError(f"oracle zonal rc={rc}")
     return {"count": cnt, "mean": mean, "variance": var, "min": mn, "max": mx}
+
+
+def quickshift_smooth(image_f64, sigma):
+    """_quickshift.py: `image = ndi.gaussian_filter(image, [sigma, sigma, 0])` on the float64 (H, W, C) image, after the Lab conversion
+    and before `* ratio`."""
+    out = np.ascontiguousarray(image_f64, np.float64)
+    if float(sigma) > 1e-15:
+        w, lw = gaussian_weights_f64(sigma)
+        out = _correlate1d_reflect(out, w, lw, 0)
+        out = _correlate1d_reflect(out, w, lw, 1)
+    return np.ascontiguousarray(out)
 
 
 def quickshift_core(image_f64, noise, kernel_size, max_dist):

@@ -14,7 +14,7 @@ warnings.filterwarnings("ignore")
 import scipy.ndimage as ndi  # noqa: E402
 import skimage  # noqa: E402
 from skimage.color import rgb2lab  # noqa: E402
-from skimage.segmentation import slic  # noqa: E402
+from skimage.segmentation import slic, quickshift  # noqa: E402
 from skimage.segmentation import slic_superpixels as _ss  # noqa: E402
 
 from gen_goldens import obia_normalize, synth_dn  # noqa: E402
@@ -75,5 +75,22 @@ def main():
     case("spacing_mask_96x128x4", synth_dn(H, W, 4, seed=29), dict(n_segments=40, compactness=0.4), 0, mask=mask, spacing=[1.0, 0.6, 1.7])
 
 
+def quickshift_cases():
+    qs = {}
+    for i, (H, W, C, ks, md, sg, lab) in enumerate([(36, 44, 3, 3, 10, 1.5, True), (40, 52, 4, 2, 6, 0.8, False), (30, 30, 1, 5, 10, 2.5, False)]):
+        raw = synth_dn(H, W, C, seed=40 + i)
+        img64 = obia_normalize(raw.astype(np.float32)).astype(np.float64)   # (0.18.3's kernel is float64-only, as in gen_goldens.py)
+        out = quickshift(img64, ratio=0.7, kernel_size=ks, max_dist=md, sigma=sg, convert2lab=lab, random_seed=42)
+        feat = rgb2lab(img64) if lab else img64
+        qs[f"raw{i}"] = raw
+        qs[f"feat{i}"] = feat                                                  # the image the smoothing starts from
+        qs[f"smoothed{i}"] = ndi.gaussian_filter(feat, [sg, sg, 0])
+        qs[f"labels{i}"] = out.astype(np.int32)
+        qs[f"par{i}"] = np.array([ks, md, sg, 0.7, float(lab)], np.float64)
+    np.savez_compressed(os.path.join(HERE, "quickshift_sigma.npz"), **qs)
+    print("quickshift_sigma", 3, "cases")
+
+
 if __name__ == "__main__":
     main()
+    quickshift_cases()

@@ -30,6 +30,33 @@ def test_quickshift_vs_skimage_goldens():
         assert lab.min() == 0 and lab.max() == n_l - 1          # consecutive ids by root order
 
 
+def test_quickshift_with_sigma_vs_skimage_goldens(oracle):
+    """sigma (the Gaussian pre-smoothing of _quickshift.py, float64) against scikit-image's labels (tests/golden/quickshift_sigma.npz)
+    and, without the Lab conversion, against the oracle on a random raster."""
+    from obia_amd.segmentation import quickshift
+    z = np.load(os.path.join(GOLD, "quickshift_sigma.npz"))
+    for i in range(3):
+        ks, md, sg, ratio, lab_flag = z[f"par{i}"]
+        raw = z[f"raw{i}"].astype(np.float32)
+        lab = quickshift(raw, ratio=float(ratio), kernel_size=float(ks), max_dist=float(md), sigma=float(sg), convert2lab=bool(lab_flag),
+                         random_seed=42, _normalize_bands=True)
+        gold = z[f"labels{i}"]
+        ari = adjusted_rand_index(lab, gold)
+        n_l, n_g = len(np.unique(lab)), len(np.unique(gold))
+        assert ari >= 0.99, f"case {i}: ARI {ari} ({(lab != gold).mean():.3%} px differ)"
+        assert abs(n_l - n_g) <= max(1, 0.02 * n_g)
+    rs = np.random.RandomState(11)
+    H, W, C = 75, 93, 4
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.clip(np.stack([((yy // 19 + xx // 23 + c) % 3) / 2.0 for c in range(C)], -1) + 0.08 * rs.normal(size=(H, W, C)), 0, 1).astype(np.float32)
+    noise = np.random.RandomState(5).normal(scale=0.00001, size=(H, W))
+    ref = oracle.quickshift_core(oracle.quickshift_smooth(img.astype(np.float64), 1.3) * 0.5, noise, 3.0, 8.0)
+    out = quickshift(img, ratio=0.5, kernel_size=3.0, max_dist=8.0, sigma=1.3, convert2lab=False, random_seed=5)
+    assert adjusted_rand_index(out, ref) >= 0.99 and abs(len(np.unique(out)) - len(np.unique(ref))) <= max(1, 0.02 * len(np.unique(ref)))
+    with pytest.raises(ValueError):
+        quickshift(img, sigma=-1.0, convert2lab=False)
+
+
 def test_quickshift_vs_oracle_nolab_and_device_entry(oracle):
     from obia_amd.segmentation import quickshift, create_segments
     rs = np.random.RandomState(3)

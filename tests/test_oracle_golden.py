@@ -120,6 +120,21 @@ def test_quickshift_small_bit_exact(oracle):
         assert np.array_equal(out, z[f"labels{i}"]), f"case {i}: {(out != z[f'labels{i}']).sum()} px differ"
 
 
+def test_quickshift_with_sigma_bit_exact(oracle):
+    """quickshift(..., sigma=...): `ndi.gaussian_filter(image, [sigma, sigma, 0])` on the float64 image after the Lab conversion,
+    before `* ratio` (_quickshift.py) -- the smoothed float64 image to the last bit or two (the weights go through `exp`, whose last bit
+    differs between the NumPy that made the fixture and the one that runs this test; a float64 result has no float32 rounding to hide
+    that), the labels exact (gen_goldens_sigma.py)."""
+    z = np.load(os.path.join(GOLD, "quickshift_sigma.npz"))
+    for i in range(3):
+        ks, md, sg, ratio, _lab = z[f"par{i}"]
+        sm = oracle.quickshift_smooth(z[f"feat{i}"], float(sg))
+        assert np.abs(sm - z[f"smoothed{i}"]).max() <= 4e-16 * np.abs(z[f"smoothed{i}"]).max(), f"case {i}: smoothed image differs"
+        noise = np.random.RandomState(42).normal(scale=0.00001, size=sm.shape[:2])
+        out = oracle.quickshift_core(sm * ratio, noise, ks, md)
+        assert np.array_equal(out, z[f"labels{i}"]), f"case {i}: {(out != z[f'labels{i}']).sum()} px differ"
+
+
 @pytest.mark.parametrize("name", ["c2s_256x256x4_c10", "c3s_384x384x8_c025", "ragged_200x333x5"])
 def test_zonal_stats_checker_matches_numpy_golden(oracle, name):
     z, params = load(name)
