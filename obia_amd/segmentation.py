@@ -104,6 +104,11 @@ def slic(image, n_segments=100, compactness=10.0, max_num_iter=10, sigma=0, spac
         Computation is float32, obia's raster dtype (obia/handlers/geotif.py:100).
     mask : (H,W) bool/uint8, optional.  Keeps the reference's maskSLIC structure (spatial-only pre-pass)
         with the deterministic masked-grid seeding of DESIGN.md.
+    sigma : number or (depth, row, column) sequence -- scikit-image's Gaussian pre-smoothing (``ndi.gaussian_filter`` on the
+        (1, H, W, C) image after the Lab conversion, before ``* 1/compactness``; a number is the same width on all three axes,
+        divided by ``spacing``).  Pinned bit for bit on SciPy's filter (tests/golden/sigma*.npz).
+    spacing : (depth, row, column) sequence -- voxel size per axis as in scikit-image: the row / column differences of the distance
+        term are scaled by it.  Anything but (1, 1, 1) takes the sweep's direct path (exact, an order of magnitude slower).
     seeds : ``(centroids_yx (K,2), steps)`` -- initial centroids to use instead of the library's seeding rule, e.g.
         the output of scikit-image's own ``_get_mask_centroids`` / ``_get_grid_centroids`` (``steps`` as returned
         there: 3 values, depth axis first, or 2 values (y, x)).  CUDA tensor images only.  Not a scikit-image argument.
