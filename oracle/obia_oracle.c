@@ -196,6 +196,24 @@ int64_t obia_oracle_grid_centroids(int64_t H, int64_t W, int64_t n_segments, int
  *   nearest (H,W) int64 out
  * Window steps come from regular_grid((1,H,W), K) with K = number of centroids.
  * ------------------------------------------------------------------------------------------ */
+/* Sum mode of the centroid update (test infrastructure): 0 = the reference's -- float32 sums accumulated pixel by pixel in raster order
+ * (_slic.pyx); 1 = the HIP path's -- every feature truncated to 32-bit fixed point (`(int)(f * 2^s)`, 2^s the largest power of two with
+ * max|feature| * 2^s < 2^29), added in 64-bit integers, converted back and rounded ONCE (slic_sweep.hip: to_fixed32,
+ * slic_prep_lane_kernel).  Mode 1 exists to show that the summation order is the ONLY difference between the two paths: with it the
+ * oracle and the HIP path agree bit for bit at every compactness (tests/test_gpu_exact_sums.py). */
+static int g_sum_mode = 0;
+void obia_oracle_set_sum_mode(int mode) { g_sum_mode = mode; }
+static double fixed_point_scale(const float *image, int64_t n)
+{
+    float maxabs = 0.0f;
+    for (int64_t i = 0; i < n; ++i) { const float a = fabsf(image[i]); if (a > maxabs) maxabs = a; }
+    int sh = 0;
+    if (maxabs > 0.0f) { int e = 0; (void)frexp((double)maxabs, &e); sh = 29 - e; }
+    if (sh > 100) sh = 100;
+    if (sh < -90) sh = -90;
+    return ldexp(1.0, sh);
+}
+
 /* spacing (sy, sx): _slic.pyx scales the coordinate differences before squaring them, `dy = (sy * (cy - y)) ** 2` in the image's
  * float type (the depth term is (sz * 0) ** 2 = 0 whatever sz); (1, 1) multiplies by 1.0f, which is exact. */
 int obia_oracle_slic_core_sp(const float *image, const uint8_t *mask, float *segments,
@@ -270,6 +288,32 @@ int obia_oracle_slic_core_sp(const float *image, const uint8_t *mask, float *seg
             }
         }
         if (!change) break;
+        if (g_sum_mode == 1) {   /* the HIP path's integer sums (see g_sum_mode) */
+            const double fscale = fixed_point_scale(image, npix * C);
+            const float fs = (float)fscale;
+            const double inv_fscale = 1.0 / fscale;
+            int64_t *acc = (int64_t *)calloc((size_t)(K > 0 ? K : 1) * (size_t)(F + 1), sizeof(int64_t));
+            if (!acc) { free(distance); free(n_elems); free(max_dist_color); return OBIA_ENOMEM; }
+            for (int64_t y = 0; y < H; ++y)
+                for (int64_t x = 0; x < W; ++x) {
+                    if (mask && !mask[y * W + x]) continue;
+                    const int64_t k = nearest[y * W + x] - start_label;
+                    if (k < 0) continue;
+                    int64_t *a = acc + k * (F + 1);
+                    a[0] += 1; a[1] += y; a[2] += x;
+                    const float *px = image + (y * W + x) * C;
+                    for (int c = 0; c < C; ++c) a[3 + c] += (int64_t)(int)(px[c] * fs);
+                }
+            for (int64_t k = 0; k < K; ++k) {
+                const int64_t *a = acc + k * (F + 1);
+                const float fn = (float)(double)a[0];
+                n_elems[k] = a[0];
+                segments[k * F + 0] = (float)(double)a[1] / fn;
+                segments[k * F + 1] = (float)(double)a[2] / fn;
+                for (int c = 0; c < C; ++c) segments[k * F + 2 + c] = (float)((double)a[3 + c] * inv_fscale) / fn;
+            }
+            free(acc);
+        } else {
         /* recompute centres: sequential float32 accumulation in raster order */
         for (int64_t k = 0; k < K; ++k) n_elems[k] = 0;
         memset(segments, 0, sizeof(float) * (size_t)(K * F));
@@ -289,6 +333,7 @@ int obia_oracle_slic_core_sp(const float *image, const uint8_t *mask, float *seg
             }
         for (int64_t k = 0; k < K; ++k)
             for (int f = 0; f < F; ++f) segments[k * F + f] /= (float)n_elems[k];
+        }
         if (slic_zero) {
             for (int64_t y = 0; y < H; ++y)
                 for (int64_t x = 0; x < W; ++x) {

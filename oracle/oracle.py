@@ -68,6 +68,11 @@ def masked_grid_centroids(mask, n_segments):
     return yx, steps
 
 
+def set_sum_mode(mode):
+    """0: the reference's sequential float32 centroid sums (default); 1: the HIP path's integer sums (obia_oracle.c: g_sum_mode)."""
+    lib().obia_oracle_set_sum_mode(ctypes.c_int(int(mode)))
+
+
 def normalize(img):
     """obia normalize_band on every band (segment_boundaries.py:11-16,32-33); returns a copy."""
     out = np.ascontiguousarray(img, np.float32).copy()

@@ -92,6 +92,21 @@ def test_gaussian_weights_sum_like_numpy(oracle):
         assert oracle._pairwise_sum(a) == float(np.sum(a)), n
 
 
+def test_integer_sum_mode_of_the_oracle(oracle):
+    """`set_sum_mode(1)` swaps ONLY the centroid update's summation for the HIP path's integer sums (obia_oracle.c: g_sum_mode; used by
+    tests/test_gpu_exact_sums.py to attribute the last differences).  At compactness 10 nothing is near a tie: the golden's labels come
+    out unchanged; the centroids themselves differ in their last bits, which is the whole point."""
+    z, params = load("c2s_256x256x4_c10")
+    ref = run_oracle(oracle, z, params)
+    oracle.set_sum_mode(1)
+    try:
+        alt = run_oracle(oracle, z, params)
+    finally:
+        oracle.set_sum_mode(0)
+    assert np.array_equal(alt[0], z["labels"]) and np.array_equal(alt[1], z["labels_pre"])
+    assert not np.array_equal(alt[2], ref[2]) and np.abs(alt[2] - ref[2]).max() <= 1e-4 * np.abs(ref[2]).max()
+
+
 def test_rgb2lab_close_to_skimage(oracle):
     z, _ = load("quickstart_128x128x3")
     img = oracle.normalize(z["raw"].astype(np.float32))
