@@ -99,6 +99,12 @@ struct SlicBatch {
     int *d_head = nullptr;   // two buffers of total_cells (double-buffered per sweep); list links ride in the centroid records
     int *d_head_cur = nullptr;
     unsigned long long *d_acc = nullptr;   // [total_cent] accumulator records, see acc_record_qwords()
+    // cached candidate lists of the sweep tiles (slic_sweep.hip, "candidate lists"): allocated by slic_run_sweeps
+    int *d_tl_k = nullptr;             // [total_tiles_all][SWEEP_MAXC] centroid indices of a tile's list, ascending
+    unsigned *d_tl_fp = nullptr;       // [total_tiles_all][256] per thread: its list slot in each of its wave's four footprints (a byte each)
+    int *d_tl_meta = nullptr;          // [total_tiles_all][2] {entries (-1: no list yet, -2: the tile cannot be listed), sweep it was built in}
+    int *d_tl_req = nullptr;           // [total_tiles_all] last sweep in which a centroid that left its margin asked the tile to rebuild
+    float *d_ref = nullptr;            // [total_cent][2] position a centroid's margin is measured from
     double fscale = 1.0;
     bool exit_on_fixed_point = false;
     bool slic_zero = false;            // SLIC-zero: colour term scaled by the cluster's largest colour distance so far

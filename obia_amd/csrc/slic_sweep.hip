@@ -81,8 +81,50 @@ constexpr int PPT = 4;          // pixels per lane (vertical strip)
 #ifndef OBIA_XCD_GROUP
 #define OBIA_XCD_GROUP 2
 #endif
-constexpr int MAXC = SWEEP_MAXC;   // LDS candidate slots (two scoring rounds of 64 lanes); must stay <= 128: the slot number
-                                // rides in the low 7 bits of the scoring keys
+constexpr int MAXC = SWEEP_MAXC;   // LDS candidate slots of a tile; must stay <= 128: the slot number rides in the low 7 bits of the
+                                // scoring keys (and below 255: a byte of the footprint lists)
+
+// ---- candidate lists (round 4) ----------------------------------------------------------------------------------------
+// Which centroids can reach a tile changes little from sweep to sweep (a converging centroid moves by hundredths of a pixel),
+// but finding them -- bin heads -> list nodes -> links, an atomic slot counter, an O(n^2) rank table -- was a quarter of a
+// wave's lifetime in every one of the twenty sweeps of a batch.  A tile therefore keeps its candidates as a LIST: the centroid
+// indices in ascending order (a candidate's slot IS its rank under the reference's tie rule, lowest k wins) and, per thread, the
+// slot it scores in each of its wave's four footprints (at most 64 candidates per footprint: ONE scoring round, one key
+// register).  The list is a SUPERSET that stays valid while centroids move:
+//   (A) every centroid stays within LIST_M pixels (per axis) of a reference position `ref`; the centroid step (slic_prep_*)
+//       checks that, and a centroid that left its margin takes its new position as reference and asks every tile its window,
+//       grown by LIST_M + 1, meets to rebuild (tl_req[tile] = sweep);
+//   (B) a tile's list holds every centroid whose CURRENT window, grown by 2 * LIST_M + 2, met the tile (or the footprint)
+//       when the list was built.
+// With (A) the window of a centroid lies inside its reference window grown by LIST_M + 1 (the window bounds are monotone in
+// the position and truncated to integers), and the reference window inside the window at build time grown by LIST_M + 1 more:
+// (B) therefore contains every centroid whose window meets the tile now.  Whether a listed candidate's window really meets a
+// footprint is decided by the exact test on its freshly loaded header, as before: labels are bit-identical with and without lists.
+// A tile whose grown candidate set does not fit (dense centroids) is staged from the bins with the exact windows in every
+// sweep, as in rounds 1-3; beyond MAXC exact candidates slow_tile() takes over.
+#ifndef OBIA_LIST_MARGIN
+#define OBIA_LIST_MARGIN 2
+#endif
+constexpr int LIST_M = OBIA_LIST_MARGIN;
+constexpr int LIST_GM = LIST_M + 1;
+constexpr int LIST_G2 = 2 * LIST_M + 2;
+
+// (A): called by the centroid step for a centroid at (cy, cx) with the window [y0, y1) x [x0, x1) it just computed
+__device__ __forceinline__ void list_margin_check(const SlicProblem &P, int k, float cy, float cx, int y0, int y1, int x0, int x1,
+                                                  bool first, float *__restrict__ ref, int *__restrict__ tl_req, int sweep_id) {
+    if (!ref) return;
+    float2 *rp = reinterpret_cast<float2 *>(ref) + k;
+    if (first) { *rp = make_float2(cy, cx); return; }   // (every tile builds its list in the first sweep)
+    const float2 r = *rp;
+    if (fabsf(cy - r.x) < (float)LIST_M && fabsf(cx - r.y) < (float)LIST_M) return;
+    *rp = make_float2(cy, cx);
+    int ty_lo = (y0 - LIST_GM) / SWEEP_TH; if (y0 - LIST_GM < 0) ty_lo = 0;
+    int ty_hi = (y1 - 1 + LIST_GM) / SWEEP_TH; if (ty_hi > P.tiles_y - 1) ty_hi = P.tiles_y - 1;
+    int tx_lo = (x0 - LIST_GM) / SWEEP_TW; if (x0 - LIST_GM < 0) tx_lo = 0;
+    int tx_hi = (x1 - 1 + LIST_GM) / SWEEP_TW; if (tx_hi > P.tiles_x - 1) tx_hi = P.tiles_x - 1;
+    for (int ty = ty_lo; ty <= ty_hi; ++ty)
+        for (int tx = tx_lo; tx <= tx_hi; ++tx) tl_req[P.tile_off + ty * P.tiles_x + tx] = sweep_id;
+}
 
 // K3 + binning: finalise centroids from the accumulator records (or the seeds on the very first sweep),
 // write the centroid record {cy, cx, y0, y1, x0, x1, link, -, colour[CP]} (link: next centroid of the bin's list) and push the centroid on the
@@ -97,7 +139,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
                                                         float *__restrict__ cent, int *__restrict__ head,
                                                         int *__restrict__ head_other,
                                                         int total_cells, int *__restrict__ bin_stamp, int sweep_id,
-                                                        int k_base, int cell_base) {
+                                                        int k_base, int cell_base, float *__restrict__ ref, int *__restrict__ tl_req) {
     // exit_on_fixed_point: a centroid whose record differs from the previous sweep's stamps the bin it leaves and the
     // bin it enters with the sweep number; the sweep kernel skips a tile none of whose bins was stamped since the tile
     // was last evaluated (same candidate records => same labels, same partial sums, replayed from the tile's cache).
@@ -186,6 +228,7 @@ __global__ __launch_bounds__(256) void slic_prep_kernel(const SlicProblem *__res
     hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
     hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(link), mdc);
     if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
+    list_margin_check(P, k, cy, cx, (int)fy0, (int)fy1, (int)fx0, (int)fx1, first != 0, ref, tl_req, sweep_id);
 }
 
 // The same step with ONE LANE per centroid (round 3).  The grouped kernel above spends 16 lanes on a centroid: 22 000 waves per
@@ -201,7 +244,7 @@ __global__ __launch_bounds__(64) void slic_prep_lane_kernel(const SlicProblem *_
                                                              float *__restrict__ cent, int *__restrict__ head,
                                                              int *__restrict__ head_other,
                                                              int total_cells, int *__restrict__ bin_stamp, int sweep_id,
-                                                             int cell_base) {
+                                                             int cell_base, float *__restrict__ ref, int *__restrict__ tl_req) {
     constexpr int RS = CENT_REC + CP;
     constexpr int NQ = (CP + 3 + 1) / 2;   // 16-byte pairs of the accumulator record that are in use: colours | n | sum_y | sum_x
     {   // the bins of the NEXT sweep (see slic_prep_kernel)
@@ -286,6 +329,7 @@ __global__ __launch_bounds__(64) void slic_prep_lane_kernel(const SlicProblem *_
     hrec[0] = make_float4(cy, cx, __int_as_float((int)fy0), __int_as_float((int)fy1));
     hrec[1] = make_float4(__int_as_float((int)fx0), __int_as_float((int)fx1), __int_as_float(link), mdc);
     if (bin_stamp && moved) bin_stamp[P.cell_off + by * P.ncx + bx] = sweep_id;   // the bin it enters (or changed in)
+    list_margin_check(P, k, cy, cx, (int)fy0, (int)fy1, (int)fx0, (int)fx1, first != 0, ref, tl_req, sweep_id);
 }
 
 // float feature -> 32-bit fixed point.  fs is a power of two chosen in slic_features_finish so that |f * fs| < 2^29:
@@ -322,6 +366,11 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 }
+
+// the lane's index inside its wave from the hardware's bit counts: two instructions wherever it is needed, so that NO register
+// carries the thread index across the footprint loop (round 4: with the list state in a register the allocator spilled the
+// thread index, and its reload at the head of every footprint waited for the feature loads in flight)
+__device__ __forceinline__ int lane_now() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // one pixel straight into the global accumulator record (rare paths only): colours | n | sum_y | sum_x
 template <int CP>
@@ -422,7 +471,8 @@ __device__ __forceinline__ void slic_assign_body(
     int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
-    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg) {
+    int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg,
+    int *__restrict__ tl_k, unsigned *__restrict__ tl_fp, int *__restrict__ tl_meta, const int *__restrict__ tl_req) {
     // channels that exist: a compile-time constant in the variants compiled per padding (NCH < CP), the launch argument in the
     // others (NCH == CP: the last pre-pass sweep, SLIC-zero, the fixed-point variant).  The planes of the padded channels are NOT
     // written by the feature pass since round 3 (nine bands: 36 instead of 48 bytes per pixel): nobody may read them.
@@ -451,6 +501,8 @@ __device__ __forceinline__ void slic_assign_body(
     // (a launch covers the tiles [tile_base, total_tiles_all) of the batch: one group of problems, see slic_run_sweeps)
     const int gtile = tile_base + (((int)(blockIdx.x >> 3) / XG) * 8 + (int)(blockIdx.x & 7)) * XG + (int)(blockIdx.x >> 3) % XG;
     if (gtile >= total_tiles_all) return;
+    // the tile's list state (scalar loads that depend on the block index alone: in flight beside the problem descriptor)
+    const int l_n = tl_meta[2 * (size_t)gtile], l_built = tl_meta[2 * (size_t)gtile + 1], l_req = tl_req[gtile];
     STAMP_DECL
     constexpr int RS = CENT_REC + CP;
     // (batches of equally sized problems -- the tiler's -- need no table look-up in front of the descriptor load: one
@@ -466,12 +518,11 @@ __device__ __forceinline__ void slic_assign_body(
     const float fs = (float)fscale;             // power of two
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
-    // slot = where staging happened to put a candidate; rank = its position in ascending k (the reference's tie rule, lowest k
-    // wins, becomes a comparison of ranks: the rank rides in the low word of the pixel keys and indexes the accumulators)
+    // candidates sit in ascending k: slot = rank (the reference's tie rule, lowest k wins, becomes a comparison of slots: the slot
+    // rides in the low word of the pixel keys and indexes the accumulators)
     __shared__ __attribute__((aligned(16))) float s_col[COLLB ? MAXC : 1][COLLB ? CP : 4];   // COLLB: colours of the staged candidates (scoring)
-    __shared__ __attribute__((aligned(16))) int s_k[MAXC];   // slot -> k
-    __shared__ int s_rank[MAXC];                             // slot -> rank
-    __shared__ int s_kr[MAXC];                               // rank -> k
+    __shared__ __attribute__((aligned(16))) int s_k[MAXC];   // slot -> k, ascending: a candidate's slot is its rank
+    __shared__ unsigned char s_fls[NT / 64][64];             // list building: the footprint list of a wave before the lanes pick it up
     __shared__ unsigned long long s_acc[MAXC][AQ];
     // transposed scratch of the fold: [wave][layer = first / second run of a lane][field = colours, packed integer word][lane]
     constexpr int NF = LEAN ? 1 : CP + 1;
@@ -485,7 +536,7 @@ __device__ __forceinline__ void slic_assign_body(
     __shared__ int s_tf[LEAN ? 1 : NT / 64][FLD][NF][LEAN ? 1 : 65];    // 65: row stride that keeps the transposed reads conflict-free
     __shared__ int s_tkey[LEAN ? 1 : NT / 64][FLD][LEAN ? 1 : 64];
     __shared__ unsigned s_orph[SWEEP_TH * SWEEP_TW / 32];   // valid pixels no window reached (rare): handled after the footprints
-    __shared__ int s_cnt, s_uncacheable;
+    __shared__ int s_cnt, s_uncacheable;   // s_cnt: slot counter of the build path
 #ifdef OBIA_ABL_LDSPAD
     __shared__ int s_pad[OBIA_ABL_LDSPAD / 4];   // ablation build: LDS ballast that limits the workgroups per CU
     if (start_label == 12345) s_pad[threadIdx.x] = 1;
@@ -510,7 +561,6 @@ __device__ __forceinline__ void slic_assign_body(
     const bool wave_active = fy0 < P.H;   // a wave below the bottom edge only helps with the final flush
     const int fy1 = min(fy0 + FB, P.H);
     const int fy1_o = fy1;
-    const int yb = fy0 + PPT * (lane >> 4);
     const bool want_feat = !IGNORE_COLOR || accum_color;
     v2f f2[LEAN ? 1 : CP][PPT / 2];   // [channel][row pair]: pixels (yb, yb+1) and (yb+2, yb+3) of the lane's strip
     unsigned char mb[PPT];    // mask bytes of the lane's four pixels (turned into `valid` at the label stage: nothing waits for them earlier)
@@ -523,7 +573,6 @@ __device__ __forceinline__ void slic_assign_body(
     // centroid update) -- one call site inside the loop, so the registers are loop-carried without copies, and the
     // fold, the next scoring and the first selection run under the memory latency.  `real` = false (no next footprint):
     // every lane reads the first pixel of the current footprint -- one cache line, no branch around the loads.
-    const unsigned lrow = (unsigned)(PPT * (lane >> 4)) * (unsigned)P.W + (unsigned)(lane & 15);   // pixel 0 of the strip, relative to (fy0, fx0)
     const bool all_valid = (long long)P.n_valid == (long long)P.H * (long long)P.W;   // wave-uniform (scalar registers)
     auto fetch = [&](int fx0, int yb, unsigned lrow, int lane_o, bool real) {   // (row base and offset come in as opaque per-footprint copies)
 #ifdef OBIA_ABL_NOLOAD
@@ -565,6 +614,12 @@ __device__ __forceinline__ void slic_assign_body(
             for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) { f2[ch][0] = splat(0.0f); f2[ch][1] = splat(0.0f); }
         }
     };
+    // (first footprint: the lane's row and offset are rebuilt from the thread index at the call site -- computed once at the head of
+    // the kernel they were spilled across the staging paths and reloaded, with a full wait, in front of the loads)
+    auto fetch_first = [&]() {
+        const int lane_i = lane_now();
+        fetch(tx0, fy0 + PPT * (lane_i >> 4), (unsigned)(PPT * (lane_i >> 4)) * (unsigned)P.W + (unsigned)(lane_i & 15), lane_i, true);
+    };
     constexpr int GQ = CP + 3;   // global record / cache entry: colours, n, sum_y, sum_x
     const int tile_id = P.tile_off + tile;
     // bins whose centroids can reach the tile: candidate <=> y0_k < ty1 && y1_k > ty0 (same in x); with
@@ -603,20 +658,24 @@ __device__ __forceinline__ void slic_assign_body(
     } else if (px_counter && tile == 0 && tid == 0) {
         atomicAdd(px_counter, (unsigned long long)P.H * (unsigned long long)P.W);
     }
-    // ---- 1. stage the candidates of the tile: lanes walk the lists of the bins whose centroids can reach it ------------------
-    // The two dependent round trips of a lane's first list node (bin head -> record + link) touch no LDS: they are issued
-    // BEFORE the accumulators are cleared and the first barrier is waited for, so that clearing and barrier run under them.
-    auto bin_head = [&](int bi) { return head[P.cell_off + (by_lo + bi / nbw) * P.ncx + bx_lo + bi % nbw]; };
-    int cur = (tid < nbins) ? bin_head(tid) : -1;
+    // ---- 1. the candidates of the tile ("candidate lists" at the top of the file) ------------------------------------------------
+    // listed: the tile reads its list -- ONE round trip to the centroid indices (issued at the head of the kernel, beside the
+    // problem descriptor) and one to the headers; no bin walk, no slot counter, no ranking, one barrier.
+    const bool listed = l_n >= 0 && l_req <= l_built;    // workgroup-uniform (scalar registers)
+    int lk = -1;
+    unsigned myc4 = 0xffffffffu;   // the thread's list slot in each of its wave's four footprints, a byte each (0xff: none)
+    if (listed) {
+        if (tid < l_n) lk = tl_k[(size_t)gtile * MAXC + tid];
+        myc4 = tl_fp[(size_t)gtile * NT + tid];
+    }
     for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
     for (int i = tid; i < SWEEP_TH * SWEEP_TW / 32; i += NT) s_orph[i] = 0u;
-    if (tid < MAXC) s_k[tid] = 0x7fffffff;   // sentinel: the rank loop reads whole groups of eight entries without bound checks
-    if (tid == 0) { s_cnt = 0; s_uncacheable = 0; }
+    if (tid == 0) s_uncacheable = 0;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, rcol[CP / 4];
 #pragma unroll
     for (int q = 0; q < CP / 4; ++q) rcol[q] = r0;
     int nxt = -1;
-    auto load_node = [&](int c) {   // header, link (and colours for the colour-box bound) of one list node: one round trip
+    auto load_node = [&](int c) {   // header, link (and colours for the colour-box bound) of one centroid record: one round trip
         const float4 *src = reinterpret_cast<const float4 *>(cent + (size_t)c * RS);
         r0 = src[0]; r1 = src[1];
         if (COLLB) {
@@ -625,59 +684,139 @@ __device__ __forceinline__ void slic_assign_body(
         }
         nxt = __float_as_int(r1.z);   // the link rides in the record
     };
-    if (cur >= 0) load_node(cur);
-    __syncthreads();
-    // (the features of the wave's FIRST footprint: their HBM latency runs under the rest of the staging, the ranking and the scoring)
-    if (wave_active) fetch(tx0, yb, lrow, lane, true);
-    for (int bi = tid; bi < nbins; bi += NT) {
-        if (bi != tid) { cur = bin_head(bi); if (cur >= 0) load_node(cur); }   // (more than 256 bins: tiny steps)
-        while (cur >= 0) {
-            const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
-            const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
-            if (y0 < ty1 && y1 > ty0 && x0 < tx1 && x1 > tx0) {
-                const int slot = atomicAdd(&s_cnt, 1);
-                if (slot < MAXC) {
-                    float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
-                    dh[0] = r0; dh[1] = make_float4(r1.x, r1.y, __int_as_float(cur), r1.w);   // (slot 6 of the LDS copy: k)
-                    s_k[slot] = cur;
-                    if (COLLB) {
+    auto put_slot = [&](int slot, int k) {   // the staged copy of a record: header (slot 6: k), k table, colours
+        float4 *dh = reinterpret_cast<float4 *>(&s_hdr[slot][0]);
+        dh[0] = r0; dh[1] = make_float4(r1.x, r1.y, __int_as_float(k), r1.w);
+        s_k[slot] = k;
+        if (COLLB) {
 #pragma unroll
-                        for (int q = 0; q < CP / 4; ++q) *reinterpret_cast<float4 *>(&s_col[slot][4 * q]) = rcol[q];
+            for (int q = 0; q < CP / 4; ++q) *reinterpret_cast<float4 *>(&s_col[slot][4 * q]) = rcol[q];
+        }
+    };
+    int nc;
+    if (listed) {
+        if (lk >= 0) load_node(lk);
+        // (the features of the wave's FIRST footprint: requested behind the headers, so that the staging below waits for the
+        // headers only; their HBM latency runs under the staging and the scoring)
+        if (wave_active) fetch_first();
+        if (lk >= 0) put_slot(tid, lk);
+        nc = l_n;
+        __syncthreads();
+        STAMP(1)   // prologue + staging (up to its barrier)
+    } else {
+        // build: lanes walk the lists of the bins whose centroids can reach the tile -- candidates are the centroids whose
+        // window, grown by g, meets it (g = LIST_G2: the superset that is kept as the tile's list; g = 0: the exact set, for
+        // a tile whose superset does not fit) -- rank them by k, put them in that order and make the footprint lists.
+        int g = (l_n == -2) ? 0 : LIST_G2;
+        bool listable = g > 0;
+        for (;;) {   // (second round with g = 0 when the superset overflows: workgroup-uniform)
+            __syncthreads();
+            if (tid < MAXC) s_k[tid] = 0x7fffffff;   // sentinel: the rank loop reads whole groups of eight entries without bound checks
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            // bins whose centroids can reach the tile: candidate <=> y0_k - g < ty1 && y1_k + g > ty0 (same in x); with
+            // y0 = trunc(max(cy-2sy,0)), y1 = trunc(min(cy+2sy+1,H)) that needs cy in (ty0 - 2sy - 2 - g, ty1 + 2sy + 1 + g): one
+            // pixel of slack covers float rounding of the binning.
+            int gy_lo = (ty0 - 2 * P.sy - 2 - g) / P.sy; if (ty0 - 2 * P.sy - 2 - g < 0) gy_lo = 0;
+            int gy_hi = (ty1 + 2 * P.sy + 1 + g) / P.sy; if (gy_hi > P.ncy - 1) gy_hi = P.ncy - 1;
+            int gx_lo = (tx0 - 2 * P.sx - 2 - g) / P.sx; if (tx0 - 2 * P.sx - 2 - g < 0) gx_lo = 0;
+            int gx_hi = (tx1 + 2 * P.sx + 1 + g) / P.sx; if (gx_hi > P.ncx - 1) gx_hi = P.ncx - 1;
+            const int gbw = gx_hi - gx_lo + 1;
+            const int gbins = (gy_hi - gy_lo + 1) * gbw;
+            for (int bi = tid; bi < gbins; bi += NT) {
+                int cur = head[P.cell_off + (gy_lo + bi / gbw) * P.ncx + gx_lo + bi % gbw];
+                if (cur >= 0) load_node(cur);
+                while (cur >= 0) {
+                    const int y0 = __float_as_int(r0.z), y1 = __float_as_int(r0.w);
+                    const int x0 = __float_as_int(r1.x), x1 = __float_as_int(r1.y);
+                    if (y0 - g < ty1 && y1 + g > ty0 && x0 - g < tx1 && x1 + g > tx0) {
+                        const int slot = atomicAdd(&s_cnt, 1);
+                        if (slot < MAXC) put_slot(slot, cur);
                     }
+                    cur = nxt;
+                    if (cur >= 0) load_node(cur);
                 }
             }
-            cur = nxt;
-            if (cur >= 0) load_node(cur);
-        }
-    }
-    __syncthreads();
-    STAMP(1)   // prologue + staging (up to its barrier)
-    const int nc = s_cnt;
-    if (nc > MAXC) {   // wave-uniform (whole workgroup)
-        slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
-                                                      accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
-        return;
-    }
-    auto do_sort = [&]() {
-    // rank of every slot = number of staged candidates with a smaller k (all distinct).  Thread t ranks slot t against the whole
-    // k table with broadcast reads of four entries each -- independent LDS reads, no serial chain; the records stay where they are.
-    {
-        if (tid < nc) {
-            const int myk = s_k[tid];
-            int r = 0;
-#pragma unroll 1
-            for (int i = 0; i < nc; i += 8) {   // eight entries per step: two independent reads in flight (unstaged slots hold INT_MAX)
-                const int4 ka = *reinterpret_cast<const int4 *>(&s_k[i]), kb = *reinterpret_cast<const int4 *>(&s_k[i + 4]);
-                r += (ka.x < myk) + (ka.y < myk) + (ka.z < myk) + (ka.w < myk) + (kb.x < myk) + (kb.y < myk) + (kb.z < myk) + (kb.w < myk);
+            __syncthreads();
+            nc = s_cnt;
+            if (nc > MAXC) {   // workgroup-uniform
+                if (g > 0) { g = 0; listable = false; continue; }
+                if (tid == 0) { tl_meta[2 * (size_t)gtile] = -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id; }
+                slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
+                                                              accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
+                return;
             }
-            s_rank[tid] = r;
-            s_kr[r] = myk;
+            // rank of every slot = number of staged candidates with a smaller k (all distinct).  Thread t ranks slot t against the
+            // whole k table with broadcast reads of four entries each -- independent LDS reads, no serial chain -- and moves its
+            // record to the slot of its rank.
+            {
+                int myk = 0, rk = 0;
+                if (tid < nc) {
+                    myk = s_k[tid];
+#pragma unroll 1
+                    for (int i = 0; i < nc; i += 8) {   // eight entries per step: two independent reads in flight (unstaged slots hold INT_MAX)
+                        const int4 ka = *reinterpret_cast<const int4 *>(&s_k[i]), kb = *reinterpret_cast<const int4 *>(&s_k[i + 4]);
+                        rk += (ka.x < myk) + (ka.y < myk) + (ka.z < myk) + (ka.w < myk) + (kb.x < myk) + (kb.y < myk) + (kb.z < myk) + (kb.w < myk);
+                    }
+                    r0 = *reinterpret_cast<const float4 *>(&s_hdr[tid][0]);
+                    r1 = *reinterpret_cast<const float4 *>(&s_hdr[tid][4]);
+                    if (COLLB) {
+#pragma unroll
+                        for (int q = 0; q < CP / 4; ++q) rcol[q] = *reinterpret_cast<const float4 *>(&s_col[tid][4 * q]);
+                    }
+                }
+                __syncthreads();
+                if (tid < nc) put_slot(rk, myk);
+                __syncthreads();
+            }
+            // footprint lists: the candidates whose (grown) window meets each of the wave's four footprints, at most 64 of them
+            bool ovf = false;
+            myc4 = 0xffffffffu;
+            for (int bxi = 0; wave_active && bxi < SWEEP_TW / FB; ++bxi) {
+                const int fx0 = tx0 + FB * bxi;
+                if (fx0 >= P.W) break;   // wave-uniform
+                const int fx1 = min(fx0 + FB, P.W);
+                int base = 0;
+                for (int r = 0; r < (MAXC + 63) / 64; ++r) {
+                    const int c = 64 * r + lane;
+                    bool in = false;
+                    if (c < nc) {
+                        const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
+                        const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
+                        in = (__float_as_int(h0.z) - g < fy1) && (__float_as_int(h0.w) + g > fy0) &&
+                             (__float_as_int(h1.x) - g < fx1) && (__float_as_int(h1.y) + g > fx0);
+                    }
+                    const unsigned long long m = __ballot(in);
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (in && pos < 64) s_fls[wv][pos] = (unsigned char)c;
+                    base += __popcll(m);
+                }
+                ovf |= base > 64;
+                wave_lds_sync();
+                const unsigned mine = (lane < base) ? (unsigned)s_fls[wv][lane] : 0xffu;
+                myc4 = (myc4 & ~(0xffu << (8 * bxi))) | (mine << (8 * bxi));
+                wave_lds_sync();
+            }
+            if (__syncthreads_or(ovf ? 1 : 0)) {   // (a footprint meets more than 64 candidates: clustered centroids)
+                if (g > 0) { g = 0; listable = false; continue; }
+                if (tid == 0) { tl_meta[2 * (size_t)gtile] = -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id; }
+                slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
+                                                              accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
+                return;
+            }
+            break;
         }
-        __syncthreads();
+        if (listable) {
+            if (tid < nc) tl_k[(size_t)gtile * MAXC + tid] = s_k[tid];
+            tl_fp[(size_t)gtile * NT + tid] = myc4;
+        }
+        if (tid == 0) { tl_meta[2 * (size_t)gtile] = listable ? nc : -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id; }
+        // (the features of the first footprint are requested only now: registers that are live across the build path -- the
+        // fallback to slow_tile() sits in it -- were spilled in the footprint loop)
+        if (wave_active) fetch_first();
+        STAMP(1)   // prologue + staging + ranking + lists
     }
-    };
-    do_sort();
-    STAMP(0)   // sort
+    STAMP(0)   // (sort: part of the build path since round 4)
 
     constexpr unsigned INF_BITS = 0x7f800000u;
     // ---- 2. per wave: four 16x16 footprints (one 16-row band of the 64x64 tile) ---------------------------------------
@@ -688,9 +827,7 @@ __device__ __forceinline__ void slic_assign_body(
         // ~25 registers for the whole kernel (and spill): opaque copies keep them one or two instructions away instead
         // (rebuilt from the thread index, the one vector register that is live anyway: kept across the loop, lane, yb and lrow
         // would hold three registers for the whole kernel)
-        int tid_o = threadIdx.x;
-        asm volatile("" : "+v"(tid_o));
-        const int lane_i = tid_o & 63;
+        const int lane_i = lane_now();
         const int yb_i = fy0 + PPT * (lane_i >> 4);
         const unsigned lrow_i = (unsigned)(PPT * (lane_i >> 4)) * (unsigned)P.W + (unsigned)(lane_i & 15);
         const int fx1 = min(fx0 + FB, P.W);
@@ -705,14 +842,14 @@ __device__ __forceinline__ void slic_assign_body(
         for (int j = 0; j < PPT; ++j) bk[j] = (unsigned long long)INF_BITS << 32;
 #define BK_D(j) __uint_as_float((unsigned)(bk[j] >> 32))
 
-        // ---- score the candidates, one per lane (two rounds cover MAXC = 96 slots) -------------------------------
+        // ---- score the footprint's candidates, one per lane (the footprint list holds at most 64) ----------------------
         // lb = the reference's spatial expression evaluated at the footprint point nearest to the centroid: every
         // operation is monotone, so lb <= spatial(pixel) <= d(pixel) for every pixel of the footprint.  The scoring key
         // is lb with its low 7 mantissa bits replaced by the slot number: still a lower bound (rounded DOWN), unique in
         // the wave, and the wave minimum names its slot without a ballot.
-        unsigned key[2];
-        int kkv[2];   // global centroid index of the lane's candidate
-        float clbv[COLLB ? 2 : 1];   // COLLB: its colour-box bound
+        unsigned key = 0xffffffffu;
+        int kkv = 0;         // global centroid index of the lane's candidate
+        float clbv = 0.0f;   // COLLB: its colour-box bound
         float blo[COLLB ? CP : 1], bhi[COLLB ? CP : 1];
         if (COLLB) {   // the box of this footprint: wave-uniform address, scalar loads
             const float4 *bx = reinterpret_cast<const float4 *>(fbox) + (P.fb_off + (long long)(fy0_o >> 4) * P.XB + (fx0 >> 4)) * (2 * CP / 4);
@@ -723,23 +860,19 @@ __device__ __forceinline__ void slic_assign_body(
                 bhi[4 * q] = h.x; bhi[4 * q + 1] = h.y; bhi[4 * q + 2] = h.z; bhi[4 * q + 3] = h.w;
             }
         }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int c = 64 * r + lane_i;
-            key[r] = 0xffffffffu;
-            kkv[r] = 0;
-            if (COLLB) clbv[r] = 0.0f;
+        {
+            const unsigned c = (myc4 >> (8 * bxi)) & 0xffu;   // the lane's slot in this footprint's list
             // (the float images of the footprint's edges are rebuilt here from scalar registers: kept across the
             // footprint loop they cost vector registers the visit loop needs)
             int fy0 = fy0_o, fy1 = fy1_o;
             asm volatile("" : "+s"(fy0), "+s"(fy1));
-            if (c < nc) {
+            if (c != 0xffu) {
                 const float4 h0 = *reinterpret_cast<const float4 *>(&s_hdr[c][0]);
                 const float4 h1 = *reinterpret_cast<const float4 *>(&s_hdr[c][4]);
-                kkv[r] = __float_as_int(h1.z);
+                kkv = __float_as_int(h1.z);
                 const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
                 const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
-                if (y0 < fy1 && y1 > fy0 && x0 < fx1 && x1 > fx0) {
+                if (y0 < fy1 && y1 > fy0 && x0 < fx1 && x1 > fx0) {   // the exact window of the fresh header
                     const float cy = h0.x, cx = h0.y;
                     const float ry = (cy < (float)fy0) ? (float)fy0 : ((cy > (float)(fy1 - 1)) ? (float)(fy1 - 1) : cy);
                     const float rx = (cx < (float)fx0) ? (float)fx0 : ((cx > (float)(fx1 - 1)) ? (float)(fx1 - 1) : cx);
@@ -758,10 +891,10 @@ __device__ __forceinline__ void slic_assign_body(
                                 cl += t * t;
                             }
                         }
-                        clbv[r] = cl;
+                        clbv = cl;
                         lb += cl;
                     }
-                    key[r] = (__float_as_uint(lb) & ~127u) | (unsigned)s_rank[c];      // lb >= 0, never NaN: below 0xffffffff
+                    key = (__float_as_uint(lb) & ~127u) | c;      // lb >= 0, never NaN: below 0xffffffff
                 }
             }
         }
@@ -780,7 +913,7 @@ __device__ __forceinline__ void slic_assign_body(
 #ifdef OBIA_ABL_VISITS
         int abl_visits = 0;
 #endif
-        unsigned mn = wave_umin(min(key[0], key[1]));
+        unsigned mn = wave_umin(key);
         for (;;) {
             if (mn == 0xffffffffu) break;
             if (!__ballot(__uint_as_float(mn & ~127u) <= mybest)) break;   // equality must still be visited: it can tie on k
@@ -791,20 +924,15 @@ __device__ __forceinline__ void slic_assign_body(
             // the scoring lane that holds the minimum names the candidate: its record is read from global memory at a
             // wave-uniform address -- the scalar unit loads header and colours into SGPRs, no VALU / LDS work (the kernel is
             // bound by VALU issue: every vector instruction of this loop is paid 4.4 times per footprint)
-            const unsigned long long m0 = __ballot(key[0] == mn), m1 = __ballot(key[1] == mn);
-            const int kk = m0 ? __builtin_amdgcn_readlane(kkv[0], (int)__builtin_ctzll(m0)) : __builtin_amdgcn_readlane(kkv[1], (int)__builtin_ctzll(m1));
-            key[0] = (key[0] == mn) ? 0xffffffffu : key[0];
-            key[1] = (key[1] == mn) ? 0xffffffffu : key[1];
+            const int sl = (int)__builtin_ctzll(__ballot(key == mn));   // (the keys are unique in the wave)
+            const int kk = __builtin_amdgcn_readlane(kkv, sl);
+            key = (key == mn) ? 0xffffffffu : key;
             float clb = 0.0f;   // COLLB: the candidate's colour-box bound (uniform)
-            if (COLLB) {
-                const int sl = m0 ? (int)__builtin_ctzll(m0) : (int)__builtin_ctzll(m1);
-                clb = m0 ? __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clbv[0]), sl))
-                         : __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clbv[COLLB ? 1 : 0]), sl));
-            }
+            if (COLLB) clb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clbv), sl));
             const float4 *__restrict__ crec = reinterpret_cast<const float4 *>(cent + (size_t)kk * RS);
             const float4 h0 = crec[0], h1 = crec[1];
             // the next candidate, under the latency of the loads
-            const unsigned mn_next = wave_umin(min(key[0], key[1]));
+            const unsigned mn_next = wave_umin(key);
             const float cy = h0.x, cx = h0.y;
             const int y0 = __float_as_int(h0.z), y1 = __float_as_int(h0.w);
             const int x0 = __float_as_int(h1.x), x1 = __float_as_int(h1.y);
@@ -910,7 +1038,7 @@ __device__ __forceinline__ void slic_assign_body(
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
                 const bool inimg = (yb_i + j < P.H) && (x < P.W);
-                const int kk = s_kr[(unsigned)bk[j]];   // rank -> k (rank 0 while unassigned: unused)
+                const int kk = s_k[(unsigned)bk[j]];   // slot -> k (slot 0 while unassigned: unused)
                 if (inimg && !(valid[j] && pk[j] < 0))
                     __builtin_nontemporal_store(pk[j] >= 0 ? kk - P.cent_off + start_label : start_label - 1,
                                                 lbase + (lrow_i + (unsigned)j * (unsigned)P.W));
@@ -1052,8 +1180,9 @@ __device__ __forceinline__ void slic_assign_body(
 #undef BK_D
     if (!accumulate) { STAMP_FLUSH return; }
     __syncthreads();
+    const int tid_e = wv * 64 + lane_now();   // (the thread index, rebuilt: see lane_now)
     if (s_uncacheable && store_labels == 2) {   // workgroup-uniform, rare: the orphan pixels of the tile go straight to the global records (their previous labels are in memory only when every sweep stores)
-        for (int i = tid; i < SWEEP_TH * SWEEP_TW; i += NT) {
+        for (int i = tid_e; i < SWEEP_TH * SWEEP_TW; i += NT) {
             if (!((s_orph[i >> 5] >> (i & 31)) & 1u)) continue;
             const int y = ty0 + i / SWEEP_TW, x = tx0 + i % SWEEP_TW;
             const long long pix = P.pix_off + (long long)y * P.W + x;
@@ -1072,13 +1201,13 @@ __device__ __forceinline__ void slic_assign_body(
     unsigned long long *cq = keep ? cache_q + (size_t)tile_id * MAXC * GQ : nullptr;
     // (the lean kernel without the fixed-point cache only has the three integer words of every record to send)
     constexpr int QLO = (LEAN && !FIXPT) ? CP : 0, QN = GQ - QLO;
-    for (int i = tid; i < nc * QN; i += NT) {
+    for (int i = tid_e; i < nc * QN; i += NT) {
         const int slot = i / QN, q = QLO + (i - slot * QN);
         const unsigned long long pw = s_acc[slot][PWI];
         const unsigned long long n = pw & 0xffffull;
-        if (FIXPT && keep && q == QLO) ck[1 + slot] = n ? s_kr[slot] : -1;
+        if (FIXPT && keep && q == QLO) ck[1 + slot] = n ? s_k[slot] : -1;
         if (n == 0ull) continue;   // nothing landed on this centroid
-        const int k = s_kr[slot];
+        const int k = s_k[slot];
         unsigned long long v;
         if (q < CP) { if (!FIXPT && !accum_color) continue; v = accum_color ? s_acc[slot][LEAN ? 0 : q] : 0ull; }
         else if (q == CP) v = n;
@@ -1088,7 +1217,7 @@ __device__ __forceinline__ void slic_assign_body(
         if (FIXPT && q < CP && !accum_color) continue;
         atomicAdd(&acc[(size_t)k * RQ + q], v);
     }
-    if (keep && tid == 0) { ck[0] = nc; tile_lp[tile_id] = sweep_id; }
+    if (keep && tid_e == 0) { ck[0] = nc; tile_lp[tile_id] = sweep_id; }
     STAMP(7)   // barrier + flush
     STAMP_FLUSH
 }
@@ -1100,10 +1229,12 @@ __device__ __forceinline__ void slic_assign_body(
         int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
-        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg
+        int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg,     \
+        int *__restrict__ tl_k, unsigned *__restrict__ tl_fp, int *__restrict__ tl_meta, const int *__restrict__ tl_req
 #define OBIA_ASSIGN_ARGS                                                                                               \
     probs, feat, mask, cent, head, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
-        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base, nch_arg
+        cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base, nch_arg, \
+        tl_k, tl_fp, tl_meta, tl_req
 
 // the colour sweeps and the last pre-pass sweep
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, int NCH = CP>
@@ -1181,7 +1312,7 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     hipExtLaunchKernelGGL(HIP_KERNEL_NAME(__VA_ARGS__), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
                           b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels, b.start_label,      \
                           b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter,          \
-                          b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0, b.C)
+                          b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0, b.C, b.d_tl_k, b.d_tl_fp, b.d_tl_meta, b.d_tl_req)
     // channels that exist: C of the CP = 4 * ceil(C / 4) the planes and records hold.  The two kernels that run 9 of every 10
     // sweeps come in a variant per padding (slic_assign_body: NCH); the others treat the padded channels like real ones.
     const int pad = CP - b.C;
@@ -1265,6 +1396,15 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         OBIA_HIP_TRY(hipMemsetAsync(fp.bin_stamp, 0, sizeof(int) * (size_t)b.total_cells, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(fp.tile_lp, 0, sizeof(int) * nt, ctx->stream));
     }
+    {   // candidate lists of the sweep tiles (see the top of the file)
+        const size_t nt = (size_t)b.total_tiles_all;
+        b.d_tl_k = A.get<int>(nt * MAXC);
+        b.d_tl_fp = A.get<unsigned>(nt * NT);
+        b.d_tl_meta = A.get<int>(nt * 2);
+        b.d_tl_req = A.get<int>(nt);
+        b.d_ref = A.get<float>((size_t)b.total_cent * 2);
+        if (!b.d_tl_k || !b.d_tl_fp || !b.d_tl_meta || !b.d_tl_req || !b.d_ref) return OBIA_E_NOMEM;
+    }
     int maxh_z = 1;
     for (auto &P : b.probs) if (P.H > maxh_z) maxh_z = P.H;
     if (maxh_z > 4096) maxh_z = 4096;
@@ -1321,6 +1461,9 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     auto run_all = [&](bool store_all) -> int {
         OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 513, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
+        // no tile has a list, nobody asked for a rebuild ({-1, -1} and 0: the first sweep builds every list)
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_tl_meta, 0xff, sizeof(int) * 2 * (size_t)b.total_tiles_all, ctx->stream));
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_tl_req, 0, sizeof(int) * (size_t)b.total_tiles_all, ctx->stream));
         debug_sync(ctx, "sweeps: memsets");
         if (groups.size() > 1) {   // fork: the side streams start after everything queued on the context's stream so far
             OBIA_HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));
@@ -1357,7 +1500,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
 #define LAUNCH_PREP_LANE(CPV)                                                                                         \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_lane_kernel<CPV>), dim3(cdiv(sg.kmax, 64), sg.p1 > sg.p0 ? sg.p1 - sg.p0 : 1), dim3(64), 0, \
                        sg.stream, b.d_probs, sg.p1 > sg.p0 ? sg.p0 : 0, first ? 1 : 0, zmode, b.d_seed, b.d_acc, RQ, 1.0 / b.fscale, b.d_cent,  \
-                       head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.cell0)
+                       head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.cell0, b.d_ref, b.d_tl_req)
                 if (!prep_grouped) {
                     switch (b.CP) {
                         case 4: LAUNCH_PREP_LANE(4); break;
@@ -1368,11 +1511,11 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                 } else if (RQ == 16)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<16>), dim3(cdiv(nk * 16, 256)), dim3(256), 0,
                                        sg.stream, b.d_probs, b.d_cent_prob, sg.k1, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0);
+                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0, b.d_ref, b.d_tl_req);
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(slic_prep_kernel<32>), dim3(cdiv(nk * 32, 256)), dim3(256), 0,
                                        sg.stream, b.d_probs, b.d_cent_prob, sg.k1, b.CP, first ? 1 : 0, zmode, b.d_seed, b.d_acc,
-                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0);
+                                       1.0 / b.fscale, b.d_cent, head_cur, head_nxt, sg.cell1, fp.bin_stamp, sweep_no, sg.k0, sg.cell0, b.d_ref, b.d_tl_req);
 #undef LAUNCH_PREP_LANE
                 b.d_head_cur = head_cur;
                 debug_sync(ctx, "sweeps: prep");
@@ -1407,10 +1550,12 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
                     unsigned long long *pxc = ctx->profiling ? d_px + (ignore_color ? 256 : 0) : nullptr;
                     if (gi == 0 && ctx->profiling && !ignore_color && store_labels) ctx->timing.assign_store_px += (double)b.total_pix;
                     switch (b.CP) {
-                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
                         case 8: launch_assign<8>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
+#ifndef OBIA_ONLY_CP8   /* developer builds (tools/build_variant.sh ... -DOBIA_ONLY_CP8): only the 5..8-band sweep kernels are compiled */
+                        case 4: launch_assign<4>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
                         case 12: launch_assign<12>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
                         case 16: launch_assign<16>(ctx, b, ignore_color, accumulate, accum_color, store_labels, d_orphan, fp, sweep_no, use_cache, pxc, span, sg, head_cur); break;
+#endif
                         default: set_error("bad CP"); return OBIA_E_INVALID;
                     }
                 }

@@ -690,6 +690,10 @@ static int tiled_slic_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, 
     const int nty = cdiv(H, tp->tile_size);
     OBIA_TRY(prefetch_white_plan(ctx, S, tp->white_order));               // features of all white tiles: one batch
     OBIA_TRY(tiler_run(ctx, S, false, 0, nty, -1));                       // pass 1: black tiles
+    if (std::getenv("OBIA_DEBUG_FAIL_AFTER_BLACK")) {   // test hook (tests/test_gpu_edge_cases.py): an error while the white feature pass is still on its side stream
+        set_error("debug: forced failure after the black pass");
+        return OBIA_E_INVALID;
+    }
     OBIA_TRY(prefetch_white_fetch(ctx, S));
     if (tp->white_order == 1) {                                           // pass 2, two parity classes of tile rows
         OBIA_TRY(tiler_run(ctx, S, true, 0, nty, 0));
@@ -706,6 +710,16 @@ struct obia_tiler {
     obia_ctx *ctx;
     obia::TileState S;
 };
+
+// Error path: nothing this library queued may still be running when the caller gets the error back (the white tiles'
+// feature pass runs on a side stream beside the black batch and is joined only when the white pass starts -- a failure in
+// between returned while that pass could still read the caller's raster and write arena memory the next call hands out again).
+static int fail_quiesced(obia_ctx *ctx, int rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < obia_ctx::MAX_SIDE; ++i)
+        if (ctx->side[i]) (void)hipStreamSynchronize(ctx->side[i]);
+    return rc;
+}
 
 using namespace obia;
 
@@ -727,7 +741,7 @@ obia_tiler *obia_tiler_create(obia_ctx *ctx, const float *img_local, const uint8
 
 void obia_tiler_destroy(obia_tiler *t) {
     if (!t) return;
-    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)fail_quiesced(t->ctx, 0);   // (a session dropped half-way may have left the white feature pass on its side stream)
     resolve_timing(t->ctx);
     delete t;
 }
@@ -735,7 +749,8 @@ void obia_tiler_destroy(obia_tiler *t) {
 int obia_tiler_run(obia_tiler *t, int white, int tile_row_lo, int tile_row_hi, int row_parity) {
     if (!t) { set_error("null tiler"); return OBIA_E_INVALID; }
     if (hipSetDevice(t->ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
-    OBIA_TRY(tiler_run(t->ctx, t->S, white != 0, tile_row_lo, tile_row_hi, row_parity));
+    const int rc = tiler_run(t->ctx, t->S, white != 0, tile_row_lo, tile_row_hi, row_parity);
+    if (rc != OBIA_OK) return fail_quiesced(t->ctx, rc);
     OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
     return OBIA_OK;
 }
@@ -769,7 +784,8 @@ int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count) 
 
 int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out) {
     if (!t) { set_error("null tiler"); return OBIA_E_INVALID; }
-    return tiler_finalize(t->ctx, t->S, n_segments_out);
+    const int rc = tiler_finalize(t->ctx, t->S, n_segments_out);
+    return rc == OBIA_OK ? rc : fail_quiesced(t->ctx, rc);
 }
 
 int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, int H, int W, int C,
@@ -784,7 +800,7 @@ int obia_tiled_slic_f32_dev(obia_ctx *ctx, const float *img, const uint8_t *mask
         ScopedSpan total(ctx, T_TOTAL);
         rc = tiled_slic_dev(ctx, img, mask, H, W, C, tiling, params, labels_out, n_segments_out);
     }
-    if (rc != OBIA_OK) return rc;
+    if (rc != OBIA_OK) return fail_quiesced(ctx, rc);
     OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     resolve_timing(ctx);
     return OBIA_OK;

@@ -123,6 +123,16 @@ class TorchComm:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
+    def abort(self):
+        """a rank that failed takes its communicators down, so that the neighbours blocked in a send / receive for its rows fail
+        at once instead of waiting for the process-group timeout (RCCL: the abort propagates to the peers' operations; gloo: the
+        peers see the closed connection).  Best effort: the exception that brought us here is what the caller sees."""
+        try:
+            from torch.distributed.distributed_c10d import _abort_process_group
+            _abort_process_group(self.group)
+        except Exception:   # noqa: BLE001  (older torch, or a backend without abort: the peers fall back on their timeout)
+            pass
+
     def all_gather_ints(self, values, dev):
         """every rank's list of host integers (the only collective of the driver: two integers per rank, once per call)"""
         mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self.wire_device(dev))
@@ -493,7 +503,15 @@ class ShardedTiler:
         self.engine.set_alive(alive)
 
     def run(self):
-        """all passes; returns (labels of my slab with global ids 1..N, N)"""
+        """all passes; returns (labels of my slab with global ids 1..N, N).  A rank that fails inside (a seam guard, a device
+        error) aborts the communicator before the exception leaves: its neighbours are waiting for its rows."""
+        try:
+            return self._run()
+        except BaseException:
+            self.comm.abort()
+            raise
+
+    def _run(self):
         tr_lo = self.rank * self.R
         ntr = -(-self.Hs // self.T)
         self.engine.run(False, tr_lo, tr_lo + ntr, -1)          # pass 1: black tiles, no communication

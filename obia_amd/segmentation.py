@@ -52,12 +52,15 @@ def make_params(n_segments=100, compactness=10.0, max_num_iter=10, convert2lab=N
 
 
 def spacing_zyx(spacing):
-    """scikit-image's `spacing` (voxel size per axis: depth, row, column) in the image's dtype, float32."""
+    """scikit-image's `spacing` (voxel size per axis: depth, row, column -- or (row, column), the form scikit-image >= 0.19
+    takes for a 2-D image, which the reference's pin `scikit-image>=0.23.2` implies) in the image's dtype, float32."""
     if spacing is None:
         return [1.0, 1.0, 1.0]
     s = np.ascontiguousarray(spacing, dtype=np.float32).ravel()
+    if s.shape == (2,):   # scikit-image >= 0.19 on a 2-D image: (row, column), the one-plane depth axis gets spacing 1
+        s = np.insert(s, 0, np.float32(1.0))
     if s.shape != (3,):
-        raise ValueError("spacing: a (depth, row, column) sequence of three")
+        raise ValueError("spacing: a (row, column) or (depth, row, column) sequence")
     if not np.all(np.isfinite(s)) or np.any(s <= 0):
         raise ValueError("spacing must be positive and finite")
     return [float(v) for v in s]
@@ -74,8 +77,10 @@ def sigma_zyx(sigma, spacing=None):
         s /= np.asarray(spacing_zyx(spacing), np.float32)
     else:
         s = np.array(sigma, dtype=np.float32).ravel()
+        if s.shape == (2,):   # scikit-image >= 0.19 on a 2-D image: (row, column), no smoothing along the one-plane depth axis
+            s = np.insert(s, 0, np.float32(0.0))
         if s.shape != (3,):
-            raise ValueError("sigma: a number or a (depth, row, column) sequence of three")
+            raise ValueError("sigma: a number, a (row, column) or a (depth, row, column) sequence")
     if not np.all(s >= 0):
         raise ValueError("sigma must be >= 0")
     return [float(v) for v in s]

@@ -66,7 +66,7 @@ def test_host_argument_checks_happen_before_device_use():
     with pytest.raises(ValueError):
         slic(img, sigma=-2)            # (sigma >= 0 is supported since round 3: tests/test_gpu_sigma.py)
     with pytest.raises(ValueError):
-        slic(img, sigma=[1, 2])
+        slic(img, sigma=[1, 2, 3, 4])   # (two elements are the (row, column) form of scikit-image >= 0.19)
     with pytest.raises(ValueError):
         slic(img, spacing=(1, -1, 1))
     with pytest.raises(IndexError):

@@ -23,3 +23,12 @@ def test_the_check_recognises_the_pattern():
     assert c.SHIFT.search("\tv_lshlrev_b64 v[38:39], v47, v[38:39]").group(2) == "47"
     assert c.SHIFT.search("\tv_lshlrev_b64 v[0:1], 6, v[12:13]") is None          # an immediate amount is not the pattern
     assert c.SHIFT.search("\tv_ashrrev_i64 v[2:3], v7, v[4:5]").group(1) == "v_ashrrev_i64"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "libobia_oracle.so")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"),
+                    reason="oracle not built / no llvm-objdump")
+def test_the_check_fails_when_it_scanned_nothing():
+    """a file without device code (here: the host-only oracle library) must not pass as "0 bad shifts" """
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_shift64.py"), os.path.join(ROOT, "oracle", "libobia_oracle.so")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "EMPTY" in r.stdout, r.stdout + r.stderr

@@ -176,6 +176,46 @@ def test_eight_slabs_as_threads_of_one_process(oracle):
     assert sum(out[r][2]["foreign_ids"] for r in range(world)) > 0
 
 
+def test_a_failing_rank_aborts_the_group_instead_of_leaving_its_neighbours_waiting(oracle):
+    """an exception on ONE rank inside ShardedTiler.run() (here: its engine fails in the second white class) must take
+    the communicator down from inside run() -- the neighbours are blocked waiting for that rank's seam rows -- so that every rank
+    fails within seconds, not after the mailbox / process-group timeout."""
+    import threading
+    import time
+    from obia_amd.distributed import ShardedTiler, ThreadComm
+    world, R, H, W = 3, 2, 300, 120
+    kw = dict(tile_size=50, buffer=8, crown_radius=3, pixel_size=(1.0, 1.0), compactness=10.0)
+    img = synth(H, W, 3, seed=4)
+    comms = ThreadComm.make(world)
+    errs = {}
+
+    class FailingEngine(OracleEngine):
+        def run(self, white, tr_lo, tr_hi, parity=-1):
+            if white and parity == 1:
+                raise RuntimeError("engine failure on one rank")
+            return super().run(white, tr_lo, tr_hi, parity)
+
+    def run(c):
+        T = kw["tile_size"]
+        lo, hi = c.rank * R * T, min(H, (c.rank + 1) * R * T)
+        eng = FailingEngine if c.rank == 1 else OracleEngine
+        t = ShardedTiler(torch.from_numpy(img[lo:hi].copy()), None, H, R, T, kw["buffer"], comm=c,
+                         engine_factory=lambda im, m, Hg, row0, extra: eng(im, m, Hg, row0, dict(kw)))
+        try:
+            t.run()
+        except BaseException as e:   # (no abort() here: run() itself must have done it)
+            errs[c.rank] = repr(e)
+    t0 = time.time()
+    th = [threading.Thread(target=run, args=(c,), daemon=True) for c in comms]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for the failed one"
+    assert set(errs) == {0, 1, 2} and "engine failure" in errs[1], errs
+    assert time.time() - t0 < 60
+
+
 def test_sharded_driver_rejects_small_tiles_and_unknown_kwargs():
     """tile_size <= 2 * buffer + 1 breaks the seam protocol: refused up front, like unknown SLIC kwargs."""
     import inspect

@@ -230,3 +230,24 @@ def test_coarse_segmentation_of_a_big_raster_keeps_64_bit_coordinate_sums():
         y0, y1 = int(ys.min()), int(ys.max())
         assert y1 - y0 <= 1.4 * S, f"segment {v} spans rows {y0}..{y1}"
         assert abs(cy[v - 1] - 0.5 * (y0 + y1)) <= 0.15 * S
+
+
+def test_failed_tiled_call_leaves_nothing_running_and_the_context_reusable(monkeypatch):
+    """the white tiles' feature pass runs on a side stream beside the black batch and is joined when the white pass
+    starts.  A failure in between must not return while that pass is still reading the raster / writing arena memory: the call
+    is made to fail right after the black pass (test hook), the raster is dropped at once, and the SAME context must then
+    produce exactly what a fresh one does."""
+    from obia_amd import _lib
+    from obia_amd.tiling import create_tiled_segments
+    kw = dict(tile_size=128, buffer=16, crown_radius=3, pixel_size=(1.0, 1.0))
+    img = torch.as_tensor(synth(400, 420, 8, seed=21)).cuda()
+    ctx = _lib.Context(0)
+    monkeypatch.setenv("OBIA_DEBUG_FAIL_AFTER_BLACK", "1")
+    with pytest.raises(ValueError, match="forced failure"):
+        create_tiled_segments(img.clone(), ctx=ctx, **kw)   # (the clone is freed as soon as the call raises)
+    monkeypatch.delenv("OBIA_DEBUG_FAIL_AFTER_BLACK")
+    junk = torch.full((400, 420, 8), float("nan"), device="cuda")   # whatever took the freed raster's place
+    lab, n = create_tiled_segments(img, ctx=ctx, **kw)
+    ref, n_ref = create_tiled_segments(img, ctx=_lib.Context(0), **kw)
+    del junk
+    assert n == n_ref and torch.equal(lab, ref)

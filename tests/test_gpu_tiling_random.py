@@ -5,7 +5,8 @@ the centroid means of the HIP path are exact sums rounded once, the reference's 
 by pixel in raster order ("centroid sums"): the colours of a centroid differ by ~1e-6 relative, and at low compactness
 (colour-dominated distances) a pixel whose two best candidates tie within that flips.  One such case in ~1 500 random ones so far (seed
 172: 4 pixels); a case whose compactness is below 5 may therefore differ in <= 1e-4 of its pixels with equal segment counts, exactly the
-bar of the single-raster random parity (tests/test_gpu_random_parity.py).
+bar of the single-raster random parity (tests/test_gpu_random_parity.py) -- and must then ALSO be pixel-identical to the oracle tiler
+run with the HIP path's integer centroid sums, so that nothing but that summation can hide in the tolerance.
 (oracle/tiler.py itself stays "parity unpinned", DESIGN.md 2: this pins the HIP tile loops on the restatement.)"""
 import os
 
@@ -88,6 +89,17 @@ def test_random_tiled_case_vs_oracle(oracle, seed):
     lab, n = create_tiled_segments(torch.as_tensor(img).cuda(), input_mask=mask, **kw)
     lab = lab.cpu().numpy()
     check_against_oracle(lab, n, ref, n_ref, kw, f"seed {seed} {img.shape} {kw}")
+    if kw["compactness"] < 5.0:
+        # the tolerance above is for the centroid sums alone.  So that a real regression of a few pixels in the tile loops (seams,
+        # corner squares, the tile_any branch) cannot hide in it, the same case must ALSO equal, pixel for pixel, the oracle tiler run
+        # with the HIP path's integer centroid sums (oracle.set_sum_mode(1): every other operation stays the reference's).
+        # The comparison above is the parity evidence, this one is the regression guard.
+        oracle.set_sum_mode(1)
+        try:
+            ref1, n_ref1 = tiler.create_tiled_segments(img, mask, **kw)
+        finally:
+            oracle.set_sum_mode(0)
+        assert n == n_ref1 and np.array_equal(lab, ref1), f"seed {seed}: {(lab != ref1).sum()} px differ from the oracle tiler with integer sums"
     if mask is not None:
         assert (lab[~mask] == 0).all()
     if n:
