@@ -210,7 +210,13 @@ def main():
     # OBIA_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE card (seam rows staged through
     # the host); the real runs use RCCL ("nccl") with one rank per GPU.
     backend = os.environ.get("OBIA_BENCH_BACKEND", "nccl")
-    gpu = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and world > n_dev:
+        # RCCL needs one device per rank; ranks stacked on a card are a rehearsal and must say so (OBIA_BENCH_BACKEND=gloo)
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {n_dev}.  To rehearse the sharded path "
+                         "with several ranks on one card set OBIA_BENCH_BACKEND=gloo (seam rows staged through the host; not a scaling number)")
+    gpu = local_rank % n_dev
+    wire = "RCCL send/recv over xGMI" if backend == "nccl" else f"{backend} (REHEARSAL: seam rows staged through the host, {min(world, n_dev)} device(s) for {world} ranks)"
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     dist = None
@@ -235,7 +241,7 @@ def main():
         H = Hg // world
         row0 = rank * H
         workload = (f"{Hg}x{W}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[3])"
-                    + (f", {world} slabs of {H} rows, seam exchange over RCCL send/recv" if world > 1 else ", whole raster on one GPU"))
+                    + (f", {world} slabs of {H} rows, seam exchange over {wire}" if world > 1 else ", whole raster on one GPU"))
     elif world == 1:
         H = W = args.size
         workload = f"{H}x{W}x{C} create_tiled_segments(tile={args.tile}, overlap={args.buffer}) + zonal stats (BASELINE configs[2])"
@@ -245,7 +251,7 @@ def main():
         H = args.size           # every GPU gets a slab of the size of the N = 1 raster: fixed work per GPU
         row0 = rank * H
         workload = (f"{world * H}x{W}x{C} raster sharded over {world} GPUs ({H}-row slab per GPU = the N = 1 workload), "
-                    f"tile={args.tile}, overlap={args.buffer}, seam exchange over RCCL send/recv")
+                    f"tile={args.tile}, overlap={args.buffer}, seam exchange over {wire}")
     if world == 1:
         img = synth_raster(H, W, C, seed=rank, device=dev, row0=row0, host_rng=args.host_rng)
         mask = torch.ones((H, W), dtype=torch.uint8, device=dev)
@@ -262,21 +268,29 @@ def main():
     ctx.set_profiling(1)
     kw = dict(tile_size=args.tile, buffer=args.buffer, crown_radius=5, pixel_size=(0.5, 0.5), compactness=args.compactness, ctx=ctx)
 
-    def step():
+    def step(profile=False):
         if world == 1:
             lab, n = create_tiled_segments(img, input_mask=mask, **kw)
             t_seg = ctx.timing()
             st = zonal_stats(img, lab, n_labels=n, ctx=ctx)
         else:
             t = ShardedTiler(img, mask, world * H, H // args.tile, args.tile, args.buffer, 5, (0.5, 0.5), ctx=ctx,
-                             ext_image=ext_img, ext_mask=ext_mask, compactness=args.compactness)
+                             ext_image=ext_img, ext_mask=ext_mask, compactness=args.compactness, profile=profile)
             lab, n = t.run()
             halo_img, dense, n_owned = t.owned_labels()
+            t.clock.lap("owned_labels_ms")
             t.close()
             t_seg = ctx.timing()
             st = zonal_stats(halo_img, dense, n_labels=n_owned, ctx=ctx)   # every segment counted once, by its owner
+            if profile:
+                torch.cuda.synchronize()
+                t.clock.lap("zonal_ms")
+                phase_ms.clear()
+                phase_ms.update(t.clock.ms)
         t_z = ctx.timing()
         return lab, n, st, t_seg, t_z
+
+    phase_ms = {}   # N > 1: host clock per phase of the sharded call, from the breakdown step after the timed region
 
     def barrier():
         if dist is not None:
@@ -335,7 +349,7 @@ def main():
     barrier()
     dt = time.time() - t0
     ctx.set_profiling(1)
-    _, _, _, t_seg, t_z = step()   # the breakdown step (untimed)
+    _, _, _, t_seg, t_z = step(profile=True)   # the breakdown step (untimed)
     for k in ("features_ms", "prepass_ms", "assign_ms", "connectivity_ms"):
         parts[k] += t_seg[k]
     parts["zonal_ms"] += t_z["zonal_ms"]
@@ -345,6 +359,20 @@ def main():
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    phases_all = None
+    if dist is not None:
+        # every rank's phase times of the breakdown step (a device synchronisation at every phase boundary: they add up to the call,
+        # which is therefore a little slower than a timed step): the line of the first real multi-GPU run has to explain itself
+        keys = ["halo_ms", "black_ms", "import_ms", "class0_ms", "class1_ms", "export_ms", "relabel_ms", "owned_labels_ms", "zonal_ms"]
+        mine = torch.tensor([phase_ms.get(k, 0.0) for k in keys], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        tot = [float(v.sum().item()) for v in allp]
+        slow = max(range(world), key=lambda r: tot[r])
+        phases_all = {"source": "one sharded call after the timed region with the device synchronised at every phase boundary (host clock)",
+                      "slowest_rank": slow, "slowest_rank_ms": {k: round(float(allp[slow][i].item()), 3) for i, k in enumerate(keys)},
+                      "max_over_ranks_ms": {k: round(max(float(v[i].item()) for v in allp), 3) for i, k in enumerate(keys)},
+                      "total_ms_per_rank": [round(x, 3) for x in tot]}
     fp_leg = timed_fixed_point_leg()
 
     def compactness_leg(c):
@@ -481,7 +509,8 @@ def main():
             "dtype": "f32", "data": "synthetic" + (" (NumPy RandomState on the host)" if args.host_rng else " (SURVEY 8d formula, noise drawn on the device)"),
             "config": {"workload": workload, "tile_size": args.tile, "buffer": args.buffer, "crown_radius": 5,
                        "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
-                       "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu"},
+                       "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu",
+                       "backend": (backend if world > 1 else None), "devices": (min(world, n_dev) if world > 1 else 1)},
             "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false,{C}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -501,6 +530,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(C, args.tile, args.buffer, 5, 0.5, args.compactness)
         else:
             out["cpu_baseline"] = None
+        if phases_all is not None:
+            out["sharded_phases"] = phases_all
         out["with_exit_on_fixed_point"] = fp_leg
         out["compactness_0.25"] = c025_leg
         out["quickshift"] = qs_leg

@@ -97,7 +97,8 @@ __device__ __forceinline__ void lunite(unsigned short *par, int a, int b) {
 }
 
 __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
-                                                      int *__restrict__ parent, int *__restrict__ size, int mask_label) {
+                                                      int *__restrict__ parent, int *__restrict__ size, int mask_label,
+                                                      unsigned long long *__restrict__ lrbits) {
     __shared__ int s_lab[CT_N];
     __shared__ unsigned short s_par[CT_N];
     __shared__ int s_cnt[CT_N];
@@ -161,7 +162,13 @@ __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restric
         const long long g = P.pix_off + (long long)y * P.W + x;
         const int r = rloc[j];
         parent[g] = r >= 0 ? (int)(P.pix_off + (long long)(ty0 + r / CT_W) * P.W + tx0 + r % CT_W) : -1;
-        size[g] = s_cnt[i];      // non-zero only at local roots
+        // the pixel count of a tile-local component is written at its local root ONLY (a few words per tile instead of four bytes
+        // per pixel written here and read again by cc_flatten_kernel), and the local roots are flagged in a bitmap: size[] of any
+        // other pixel is never read (round 4)
+        if (r == i) {
+            size[g] = s_cnt[i];
+            atomicOr(&lrbits[g >> 6], 1ull << (g & 63));
+        }
     }
 }
 
@@ -195,7 +202,8 @@ __global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restric
 
 // flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
 __global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n,
-                                                         unsigned long long *__restrict__ rootbits) {
+                                                         unsigned long long *__restrict__ rootbits,
+                                                         const unsigned long long *__restrict__ lrbits) {
     // four pixels per lane, chased in lockstep: the dependent parent loads of the four chains are in flight together
     constexpr int FU = 4;
     for (long long i0 = (long long)blockIdx.x * blockDim.x * FU; i0 < n; i0 += (long long)gridDim.x * blockDim.x * FU) {
@@ -223,21 +231,21 @@ __global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ paren
         }
         // one bit per pixel: "is a root".  The ranking passes read this map (1/8 byte per pixel) and the sizes of the roots instead
         // of parent[] and size[] of every pixel (a wave's 64 pixels are consecutive and 64-aligned: one word per wave and u)
+        unsigned long long lrw[FU];   // the local-root flags of the wave's 64 pixels (cc_tile_kernel)
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const unsigned long long bal = __ballot(r[u] >= 0 && r[u] == (int)idx[u]);
             const long long first = idx[u] - (threadIdx.x & 63);
             if ((threadIdx.x & 63) == 0 && first < n) rootbits[first >> 6] = bal;
+            lrw[u] = first < n ? lrbits[first >> 6] : 0ull;   // (wave-uniform address)
         }
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             if (r[u] < 0) continue;
             parent[idx[u]] = r[u];   // roots only move to smaller indices, final value is the root
-            // size[] arrives with the pixel count of every tile-local component at its local root: a local root that is
-            // not the global root adds its count to the global root (which keeps its own); entries that are not roots
-            // are not read afterwards
-            const int ls = size[idx[u]];
-            if (ls > 0 && r[u] != (int)idx[u]) atomicAdd(&size[r[u]], ls);
+            // size[] holds the pixel count of every tile-local component at its local root (flagged in lrbits): a local root that is
+            // not the global root adds its count to the global root (which keeps its own); size[] of other pixels is never read
+            if (((lrw[u] >> (threadIdx.x & 63)) & 1ull) && r[u] != (int)idx[u]) atomicAdd(&size[r[u]], size[idx[u]]);
         }
     }
 }
@@ -724,27 +732,14 @@ __global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_
 __global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__ parent, const int *__restrict__ newlab,
                                                          const int *__restrict__ target, long long n, int start_label,
                                                          int mask_label, int max_hops, int32_t *__restrict__ out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int r = parent[i];
-        int res;
-        if (r < 0) res = mask_label;
-        else {
-            int nl = newlab[r];
-            int hops = 0;
-            while (nl < 0) {
-                const int t = target[-nl - 2];
-                // a chain only leads to components that settled EARLIER: it is acyclic and at most n_small long
-                if (t < 0 || ++hops > max_hops) { nl = -1; break; }
-                nl = newlab[parent[t]];
-            }
-            res = (nl >= 0) ? nl + start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
-        }
-        out[i] = res;
-    }
+    const CcResolve R{parent, newlab, target, max_hops, start_label, mask_label};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = cc_resolve_label(R, i);
 }
 
 int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
-                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out) {
+                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out,
+                               CcResolve *deferred) {
     ScopedSpan span(ctx, T_CC);
     Arena &A = ctx->arena;
     const long long n = total_pix;
@@ -757,6 +752,9 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *block_sums = A.get<int>(3 * (size_t)nb);   // survivors | small components | their pixels (cc_rank_blocksum_kernel)
     unsigned long long *rootbits = A.get<unsigned long long>((size_t)((n + 63) / 64));   // one bit per pixel: root (cc_flatten_kernel)
     if (!rootbits) return OBIA_E_NOMEM;
+    unsigned long long *lrbits = A.get<unsigned long long>((size_t)((n + 63) / 64));     // one bit per pixel: tile-local root (cc_tile_kernel)
+    if (!lrbits) return OBIA_E_NOMEM;
+    OBIA_HIP_TRY(hipMemsetAsync(lrbits, 0, sizeof(unsigned long long) * (size_t)((n + 63) / 64), ctx->stream));
     const unsigned long long *rb = rootbits;   // the map the ranking passes read; null once the size cut has changed the roots
     int *counters = A.get<int>(8);
     if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
@@ -773,13 +771,13 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
             const long long sm = (long long)((P.H - 1) / CT_H) * P.W + (long long)((P.W - 1) / CT_W) * P.H;
             if (sm > max_seam) max_seam = sm;
         }
-        hipLaunchKernelGGL(cc_tile_kernel, dim3(max_tiles, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label);
+        hipLaunchKernelGGL(cc_tile_kernel, dim3(max_tiles, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, size, mask_label, lrbits);
         int sg = cdiv(max_seam, 256);
         if (sg > 65535) sg = 65535;
         hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
     }
     debug_sync(ctx, "cc: tile + seam");
-    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n, rootbits);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n, rootbits, lrbits);
     debug_sync(ctx, "cc: flatten");
     hipLaunchKernelGGL(cc_rank_blocksum_bits_kernel, dim3(nb), dim3(64), 0, ctx->stream, d_probs, np, size, n, block_sums, counters, rootbits);
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(3), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
@@ -876,8 +874,11 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     if (std::getenv("OBIA_DEBUG_CC"))   // developer aid: the regime of this batch
         fprintf(stderr, "[obia cc] %lld px, %d problems: %d surviving, %d small components (%d px)\n", n, np, n_surv, n_small, small_px);
     debug_sync(ctx, "cc: rank apply + small components");
-    hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
-                       mask_label, n_small + 1, labels_out);
+    if (deferred)
+        *deferred = CcResolve{parent, newlab, target, n_small + 1, start_label, mask_label};
+    else
+        hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
+                           mask_label, n_small + 1, labels_out);
     OBIA_HIP_TRY(hipGetLastError());
     if (h_n_labels_out) *h_n_labels_out = n_surv;
     return OBIA_OK;

@@ -846,7 +846,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     }
     // window steps, bins, tiles
     int cell_off = 0, tile_max = 0;
-    long long tiles_all = 0;
+    long long tiles_all = 0, m4_total = 0;
     for (int p = 0; p < np; ++p) {
         SlicProblem &P = b.probs[p];
         P.K = K[p];
@@ -860,7 +860,8 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         P.spatial_w = (float)(1.0 / ((double)stepf * (double)stepf));
         P.sp_y = (float)b.spacing[1]; P.sp_x = (float)b.spacing[2];   // np.ascontiguousarray(spacing, dtype=image dtype)
         P.direct = (P.sp_y != 1.0f || P.sp_x != 1.0f) ? 1 : 0;
-        P.pad_ = 0;
+        P.m4_off = (int)m4_total;
+        m4_total += (long long)((P.H + 3) / 4) * P.W;
         P.cell_off = cell_off;
         long long nc = (long long)P.ncy * P.ncx;
         if (cell_off + nc > 0x7fff0000LL) { set_error("too many bins in one batch"); return OBIA_E_INVALID; }
@@ -883,6 +884,8 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     }
     b.total_cells = cell_off > 0 ? cell_off : 1;
     b.total_tiles = tile_max;
+    if (m4_total > 0x7fffffffLL) { set_error("mask of the batch too large"); return OBIA_E_INVALID; }
+    b.total_m4 = m4_total > 0 ? m4_total : 1;
     OBIA_TRY(upload_async(ctx, b.d_probs, b.probs.data(), sizeof(SlicProblem) * np));
     const int RS = CENT_REC + b.CP;
     b.d_cent = A.get<float>((size_t)b.total_cent * RS);

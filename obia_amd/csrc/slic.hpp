@@ -23,7 +23,7 @@ struct SlicProblem {
     long long fb_off;    // first record of this problem in the footprint colour boxes (SlicBatch::d_fbox)
     float sp_y, sp_x;    // slic()'s `spacing` of the row / column axis as float32 (1, 1 unless the caller says otherwise)
     int direct;          // 1: every tile takes the direct (unstaged) path -- set when the spacing is not (1, 1)
-    int pad_;
+    int m4_off;          // first dword of this problem in the packed mask (SlicBatch::d_mask4): ceil(H / 4) * W dwords per problem
 };
 
 // Source window of a problem inside the caller's raster (feature preparation).
@@ -91,6 +91,9 @@ struct SlicBatch {
     double spacing[3] = {1.0, 1.0, 1.0}; // obia_slic_params::spacing_zyx
     long long total_feat_f4 = 0;       // float4 elements of d_feat (plane layout)
     uint8_t *d_mask = nullptr;         // [total_pix] or null
+    unsigned *d_mask4 = nullptr;       // the same bytes packed for the sweeps: dword (q, x) = mask of the rows 4q .. 4q+3 at column x, a byte each
+                                       // (a lane's 1x4 strip in ONE load and one register); written by slic_run_sweeps from d_mask
+    long long total_m4 = 0;            // dwords of d_mask4
     int32_t *d_labels = nullptr;       // [total_pix] problem-local labels (start_label based)
     float *d_seed = nullptr;           // [total_cent][2]
     int *d_cent_prob = nullptr;        // [total_cent]
@@ -158,8 +161,31 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b);
 // Connectivity enforcement on a batch of dense label maps laid out back to back (pix_off); labels come
 // out consecutive over the whole batch, in problem order then raster order of each component's first pixel.
 struct CcProblem { int H, W; long long pix_off; int min_size; int max_size; };   // component sizes: merge below min, cut at max
+// The last step of the enforcement -- every pixel takes the final label of its component -- as data: a caller that moves the labels
+// somewhere else anyway (the tiler scatters them into the raster's id space) asks for this instead of the dense label map and
+// resolves each pixel where it consumes it (cc_resolve_label): one pass over the batch and 8 bytes per pixel less (round 4).
+// The arrays live in the context's arena: valid until the caller rewinds it.
+struct CcResolve { const int *parent; const int *newlab; const int *target; int max_hops; int start_label; int mask_label; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ int cc_resolve_label(const CcResolve &R, long long i) {
+    const int r = R.parent[i];
+    if (r < 0) return R.mask_label;
+    int nl = R.newlab[r];
+    int hops = 0;
+    while (nl < 0) {   // a small component follows its adjacency chain
+        const int t = R.target[-nl - 2];
+        // a chain only leads to components that settled EARLIER: it is acyclic and at most n_small long
+        if (t < 0 || ++hops > R.max_hops) { nl = -1; break; }
+        nl = R.newlab[R.parent[t]];
+    }
+    return (nl >= 0) ? nl + R.start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
+}
+#endif
+// labels_out: the dense label map (always needed as scratch of the small-component replay).  deferred (nullable): when given, the
+// final relabel pass is NOT run -- labels_out holds no result -- and *deferred describes how to resolve a pixel.
 int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
-                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out);
+                               long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out,
+                               CcResolve *deferred = nullptr);
 
 // Connectivity enforcement on one dense (H,W) label map (device pointers).
 int enforce_connectivity_dev(obia_ctx *ctx, const int32_t *labels_in, int H, int W, int min_size,

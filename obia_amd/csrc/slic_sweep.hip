@@ -108,6 +108,10 @@ constexpr int MAXC = SWEEP_MAXC;   // LDS candidate slots of a tile; must stay <
 constexpr int LIST_M = OBIA_LIST_MARGIN;
 constexpr int LIST_GM = LIST_M + 1;
 constexpr int LIST_G2 = 2 * LIST_M + 2;
+#ifndef OBIA_LIST_GIVE_UP
+#define OBIA_LIST_GIVE_UP 2
+#endif
+constexpr int LIST_GIVE_UP = OBIA_LIST_GIVE_UP;   // short-lived builds in a row after which a tile stays unlisted
 
 // (A): called by the centroid step for a centroid at (cy, cx) with the window [y0, y1) x [x0, x1) it just computed
 __device__ __forceinline__ void list_margin_check(const SlicProblem &P, int k, float cy, float cx, int y0, int y1, int x0, int x1,
@@ -466,9 +470,9 @@ __device__ void slow_tile(const SlicProblem &P, int ty0, int tx0, const float *_
 template <int CP, bool MASKED, bool IGNORE_COLOR, bool FIXPT, bool SLICZERO, bool LEAN, bool COLLB, int NCH = CP>
 __device__ __forceinline__ void slic_assign_body(
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,
-    const float *__restrict__ cent, const int *__restrict__ head,
+    const unsigned *__restrict__ mask4, const float *__restrict__ cent, const int *__restrict__ head,
     int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int store_labels,
-    int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
+    int start_label, float fs, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,
     int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,
     unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,
     int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg,
@@ -502,7 +506,9 @@ __device__ __forceinline__ void slic_assign_body(
     const int gtile = tile_base + (((int)(blockIdx.x >> 3) / XG) * 8 + (int)(blockIdx.x & 7)) * XG + (int)(blockIdx.x >> 3) % XG;
     if (gtile >= total_tiles_all) return;
     // the tile's list state (scalar loads that depend on the block index alone: in flight beside the problem descriptor)
-    const int l_n = tl_meta[2 * (size_t)gtile], l_built = tl_meta[2 * (size_t)gtile + 1], l_req = tl_req[gtile];
+    // (meta: {entries | -1 no list yet | -2 not listed,  sweep of the build | short-lived builds in a row << 16})
+    const int l_n = tl_meta[2 * (size_t)gtile], l_bw = tl_meta[2 * (size_t)gtile + 1], l_req = tl_req[gtile];
+    const int l_built = l_bw < 0 ? -1 : (l_bw & 0xffff), l_streak = l_bw < 0 ? 0 : (l_bw >> 16);
     STAMP_DECL
     constexpr int RS = CENT_REC + CP;
     // (batches of equally sized problems -- the tiler's -- need no table look-up in front of the descriptor load: one
@@ -515,7 +521,9 @@ __device__ __forceinline__ void slic_assign_body(
                                                 //   n | sum(y - ty0) << 16 | sum(x - tx0) << 40   (a 64x64 tile: n <= 4096 < 2^16,
                                                 //   sums <= 4096 * 63 < 2^18 in fields of 24 bits: no field can carry into the next)
     constexpr int NPASS = (CP + 7) / 8;         // the transposed fold handles 8 colour fields per pass
-    const float fs = (float)fscale;             // power of two
+    // fs: the fixed-point scale of the colour sums, a power of two.  It comes in as a float kernel argument (a scalar register): converted
+    // from a double inside the kernel it sat in a vector register that the low-compactness kernel spilled and reloaded inside the
+    // footprint loop (round 4)
 
     __shared__ __attribute__((aligned(16))) float s_hdr[MAXC][CENT_REC];
     // candidates sit in ascending k: slot = rank (the reference's tie rule, lowest k wins, becomes a comparison of slots: the slot
@@ -563,7 +571,8 @@ __device__ __forceinline__ void slic_assign_body(
     const int fy1_o = fy1;
     const bool want_feat = !IGNORE_COLOR || accum_color;
     v2f f2[LEAN ? 1 : CP][PPT / 2];   // [channel][row pair]: pixels (yb, yb+1) and (yb+2, yb+3) of the lane's strip
-    unsigned char mb[PPT];    // mask bytes of the lane's four pixels (turned into `valid` at the label stage: nothing waits for them earlier)
+    unsigned mbw;   // mask bytes of the lane's four pixels, packed (SlicBatch::d_mask4: ONE load, one register; turned into `valid` at the
+                    // label stage: nothing waits for them earlier)
     // Addresses: one wave-uniform 64-bit base per footprint (scalar registers) plus a 32-bit lane offset -- a pixel's
     // address costs one or two vector instructions instead of a 64-bit multiply-add chain (16 rows x W x 32 B fits 32
     // bits: slic_run_sweeps limits W).  The mask bytes and the features of the four pixels are INDEPENDENT loads (all
@@ -574,24 +583,20 @@ __device__ __forceinline__ void slic_assign_body(
     // fold, the next scoring and the first selection run under the memory latency.  `real` = false (no next footprint):
     // every lane reads the first pixel of the current footprint -- one cache line, no branch around the loads.
     const bool all_valid = (long long)P.n_valid == (long long)P.H * (long long)P.W;   // wave-uniform (scalar registers)
-    auto fetch = [&](int fx0, int yb, unsigned lrow, int lane_o, bool real) {   // (row base and offset come in as opaque per-footprint copies)
+    auto fetch = [&](int fx0, int yb, int lane_o, bool real) {   // (the lane's row comes in as an opaque per-footprint copy)
 #ifdef OBIA_ABL_NOLOAD
         real = false;   // ablation build: every lane reads the footprint's first pixel (no HBM traffic for features / mask)
 #endif
         const int xx = fx0 + (lane_o & 15);
-        const long long fbase = P.pix_off + (long long)fy0 * P.W + fx0;      // wave-uniform
-        const uint8_t *mbase = mask + (MASKED ? fbase : 0);
-        unsigned off[PPT];
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) off[j] = (real && (yb + j < P.H) && (xx < P.W)) ? lrow + (unsigned)j * (unsigned)P.W : 0u;
         // a problem whose mask hides nothing (every interior tile of the tiler: n_valid == H * W, counted by
-        // count_valid_kernel) reads no mask bytes -- four of the twelve load instructions of a footprint (wave-uniform branch)
+        // count_valid_kernel) reads no mask bytes (wave-uniform branch); the others read the packed mask: the four rows of the
+        // lane's strip are the four bytes of one dword (rows past H hold zeros)
         if (MASKED && !all_valid) {
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) mb[j] = mbase[off[j]];
+            const unsigned *mbase = mask4 + ((long long)P.m4_off + (long long)(fy0 >> 2) * P.W + fx0);      // wave-uniform
+            const unsigned moff = (real && (yb < P.H) && (xx < P.W)) ? (unsigned)(lane_o >> 4) * (unsigned)P.W + (unsigned)(lane_o & 15) : 0u;
+            mbw = mbase[moff];
         } else {
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) mb[j] = (unsigned char)1;
+            mbw = 0x01010101u;
         }
         if (!LEAN && want_feat) {
             // quad-row blocks (slic.hpp): ONE 16-byte load per channel brings that channel of the lane's four pixels, the
@@ -618,7 +623,7 @@ __device__ __forceinline__ void slic_assign_body(
     // the kernel they were spilled across the staging paths and reloaded, with a full wait, in front of the loads)
     auto fetch_first = [&]() {
         const int lane_i = lane_now();
-        fetch(tx0, fy0 + PPT * (lane_i >> 4), (unsigned)(PPT * (lane_i >> 4)) * (unsigned)P.W + (unsigned)(lane_i & 15), lane_i, true);
+        fetch(tx0, fy0 + PPT * (lane_i >> 4), lane_i, true);
     };
     constexpr int GQ = CP + 3;   // global record / cache entry: colours, n, sum_y, sum_x
     const int tile_id = P.tile_off + tile;
@@ -661,16 +666,21 @@ __device__ __forceinline__ void slic_assign_body(
     // ---- 1. the candidates of the tile ("candidate lists" at the top of the file) ------------------------------------------------
     // listed: the tile reads its list -- ONE round trip to the centroid indices (issued at the head of the kernel, beside the
     // problem descriptor) and one to the headers; no bin walk, no slot counter, no ranking, one barrier.
-    const bool listed = l_n >= 0 && l_req <= l_built;    // workgroup-uniform (scalar registers)
-    int lk = -1;
+    // The low-compactness kernel keeps no lists: where the colour term decides, centroids wander by pixels per sweep on noisy bands,
+    // lists are rebuilt every other sweep and a build costs twenty uses (measured, compactness 0.25: sweep 0.294 ms per launch with
+    // lists, 0.280 without, 0.278 in round 3 -- profiles/r04_notes.md).  Its tiles are staged from the bins in every sweep.
+#ifdef OBIA_NO_LISTS   /* developer build: every sweep stages from the bins with the exact windows (A/B of the list caching) */
+    constexpr bool USE_LISTS = false;
+#else
+    constexpr bool USE_LISTS = !COLLB;
+#endif
+    const bool listed = USE_LISTS && l_n >= 0 && l_req <= l_built;    // workgroup-uniform (scalar registers)
     unsigned myc4 = 0xffffffffu;   // the thread's list slot in each of its wave's four footprints, a byte each (0xff: none)
-    if (listed) {
-        if (tid < l_n) lk = tl_k[(size_t)gtile * MAXC + tid];
-        myc4 = tl_fp[(size_t)gtile * NT + tid];
-    }
-    for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
-    for (int i = tid; i < SWEEP_TH * SWEEP_TW / 32; i += NT) s_orph[i] = 0u;
-    if (tid == 0) s_uncacheable = 0;
+    auto clear_tables = [&]() {
+        for (int i = tid; i < MAXC * AQ; i += NT) (&s_acc[0][0])[i] = 0ull;
+        for (int i = tid; i < SWEEP_TH * SWEEP_TW / 32; i += NT) s_orph[i] = 0u;
+        if (tid == 0) s_uncacheable = 0;
+    };
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, rcol[CP / 4];
 #pragma unroll
     for (int q = 0; q < CP / 4; ++q) rcol[q] = r0;
@@ -695,6 +705,11 @@ __device__ __forceinline__ void slic_assign_body(
     };
     int nc;
     if (listed) {
+        // (the list loads live inside this branch: issued at the head of the kernel their results were spilled across the other one)
+        int lk = -1;
+        if (tid < l_n) lk = tl_k[(size_t)gtile * MAXC + tid];
+        myc4 = tl_fp[(size_t)gtile * NT + tid];
+        clear_tables();   // under the latency of the list
         if (lk >= 0) load_node(lk);
         // (the features of the wave's FIRST footprint: requested behind the headers, so that the staging below waits for the
         // headers only; their HBM latency runs under the staging and the scoring)
@@ -707,7 +722,12 @@ __device__ __forceinline__ void slic_assign_body(
         // build: lanes walk the lists of the bins whose centroids can reach the tile -- candidates are the centroids whose
         // window, grown by g, meets it (g = LIST_G2: the superset that is kept as the tile's list; g = 0: the exact set, for
         // a tile whose superset does not fit) -- rank them by k, put them in that order and make the footprint lists.
-        int g = (l_n == -2) ? 0 : LIST_G2;
+        clear_tables();
+        // A list that is rebuilt in the sweep after it was built was never used: where centroids keep moving by pixels per sweep
+        // (low compactness on noisy bands) building lists costs more than the bin walk with the exact windows.  Two such builds
+        // in a row and the tile stays unlisted for the rest of the batch (it is staged like in rounds 1-3).
+        const int streak = (l_n >= 0 && sweep_id - l_built <= 1) ? l_streak + 1 : 0;
+        int g = (!USE_LISTS || l_n == -2 || streak >= LIST_GIVE_UP || sweep_id >= 0xffff) ? 0 : LIST_G2;
         bool listable = g > 0;
         for (;;) {   // (second round with g = 0 when the superset overflows: workgroup-uniform)
             __syncthreads();
@@ -741,7 +761,7 @@ __device__ __forceinline__ void slic_assign_body(
             nc = s_cnt;
             if (nc > MAXC) {   // workgroup-uniform
                 if (g > 0) { g = 0; listable = false; continue; }
-                if (tid == 0) { tl_meta[2 * (size_t)gtile] = -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id; }
+                if (tid == 0) { tl_meta[2 * (size_t)gtile] = -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id & 0xffff; }
                 slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
                                                               accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
                 return;
@@ -769,10 +789,12 @@ __device__ __forceinline__ void slic_assign_body(
                 if (tid < nc) put_slot(rk, myk);
                 __syncthreads();
             }
-            // footprint lists: the candidates whose (grown) window meets each of the wave's four footprints, at most 64 of them
+            // footprint lists: the candidates whose (grown) window meets each of the wave's four footprints, at most 64 of them.
+            // A tile with at most 64 candidates needs none: lane l scores slot l in every footprint (the exact window test of
+            // the scoring sorts out the rest) -- the usual case of a tile that is staged from the bins in every sweep.
             bool ovf = false;
-            myc4 = 0xffffffffu;
-            for (int bxi = 0; wave_active && bxi < SWEEP_TW / FB; ++bxi) {
+            myc4 = (nc <= 64 && lane < nc) ? (unsigned)lane * 0x01010101u : 0xffffffffu;
+            for (int bxi = 0; nc > 64 && wave_active && bxi < SWEEP_TW / FB; ++bxi) {
                 const int fx0 = tx0 + FB * bxi;
                 if (fx0 >= P.W) break;   // wave-uniform
                 const int fx1 = min(fx0 + FB, P.W);
@@ -799,7 +821,7 @@ __device__ __forceinline__ void slic_assign_body(
             }
             if (__syncthreads_or(ovf ? 1 : 0)) {   // (a footprint meets more than 64 candidates: clustered centroids)
                 if (g > 0) { g = 0; listable = false; continue; }
-                if (tid == 0) { tl_meta[2 * (size_t)gtile] = -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id; }
+                if (tid == 0) { tl_meta[2 * (size_t)gtile] = -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id & 0xffff; }
                 slow_tile<CP, MASKED, IGNORE_COLOR, SLICZERO>(P, ty0, tx0, feat, mask, cent, head, labels, acc, RQ, accumulate,
                                                               accum_color, start_label, fs, store_labels, orphan_flag, sweep_id, nch_rt);
                 return;
@@ -810,7 +832,7 @@ __device__ __forceinline__ void slic_assign_body(
             if (tid < nc) tl_k[(size_t)gtile * MAXC + tid] = s_k[tid];
             tl_fp[(size_t)gtile * NT + tid] = myc4;
         }
-        if (tid == 0) { tl_meta[2 * (size_t)gtile] = listable ? nc : -2; tl_meta[2 * (size_t)gtile + 1] = sweep_id; }
+        if (tid == 0) { tl_meta[2 * (size_t)gtile] = listable ? nc : -2; tl_meta[2 * (size_t)gtile + 1] = (sweep_id & 0xffff) | (streak << 16); }
         // (the features of the first footprint are requested only now: registers that are live across the build path -- the
         // fallback to slow_tile() sits in it -- were spilled in the footprint loop)
         if (wave_active) fetch_first();
@@ -1026,7 +1048,7 @@ __device__ __forceinline__ void slic_assign_body(
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const bool inimg = (yb_i + j < P.H) && (x < P.W);
-            valid[j] = inimg && (mb[j] != 0);
+            valid[j] = inimg && (((mbw >> (8 * j)) & 0xffu) != 0u);
             const bool assigned = valid[j] && ((unsigned)(bk[j] >> 32) < INF_BITS);
             pk[j] = assigned ? (int)(unsigned)bk[j] : -1;
             // a valid pixel no window reaches keeps the previous sweep's label (`nearest` is only initialised once,
@@ -1114,7 +1136,7 @@ __device__ __forceinline__ void slic_assign_body(
         STAMP(5)   // run merge
         {   // the feature registers are free: request the next footprint (the ONLY call site inside the loop)
             const bool has_next = (bxi + 1 < SWEEP_TW / FB) && (fx0 + FB < P.W);   // wave-uniform
-            fetch(has_next ? fx0 + FB : fx0, yb_i, lrow_i, lane_i, has_next);
+            fetch(has_next ? fx0 + FB : fx0, yb_i, lane_i, has_next);
         }
         if (!accumulate || FOLD_LAYERS == 0) continue;
         // transposed fold.  Colours: lane (fld, g) walks the strips 8g .. 8g+7 of colour field fld, layer by layer.  The packed
@@ -1224,15 +1246,15 @@ __device__ __forceinline__ void slic_assign_body(
 
 #define OBIA_ASSIGN_PARAMS                                                                                             \
     const SlicProblem *__restrict__ probs, const float *__restrict__ feat, const uint8_t *__restrict__ mask,             \
-        const float *__restrict__ cent, const int *__restrict__ head,                                                    \
+        const unsigned *__restrict__ mask4, const float *__restrict__ cent, const int *__restrict__ head,                                                    \
         int32_t *__restrict__ labels, unsigned long long *__restrict__ acc, int RQ, int accumulate, int store_labels,     \
-        int start_label, double fscale, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
+        int start_label, float fs, const int *__restrict__ bin_stamp, int *__restrict__ tile_lp,                    \
         int *__restrict__ cache_k, unsigned long long *__restrict__ cache_q, int sweep_id, int use_cache,                 \
         unsigned long long *__restrict__ px_counter, const int *__restrict__ tile_prob, int total_tiles_all,              \
         int *__restrict__ orphan_flag, int tiles_per_prob, const float *__restrict__ fbox, int tile_base, int nch_arg,     \
         int *__restrict__ tl_k, unsigned *__restrict__ tl_fp, int *__restrict__ tl_meta, const int *__restrict__ tl_req
 #define OBIA_ASSIGN_ARGS                                                                                               \
-    probs, feat, mask, cent, head, labels, acc, RQ, accumulate, store_labels, start_label, fscale, bin_stamp, tile_lp, \
+    probs, feat, mask, mask4, cent, head, labels, acc, RQ, accumulate, store_labels, start_label, fs, bin_stamp, tile_lp, \
         cache_k, cache_q, sweep_id, use_cache, px_counter, tile_prob, total_tiles_all, orphan_flag, tiles_per_prob, fbox, tile_base, nch_arg, \
         tl_k, tl_fp, tl_meta, tl_req
 
@@ -1310,8 +1332,8 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
     for (auto &P : b.probs) if (P.tiles_x * P.tiles_y != tpp) tpp = 0;
 #define LAUNCH_K_(...)                                                                                               \
     hipExtLaunchKernelGGL(HIP_KERNEL_NAME(__VA_ARGS__), grid, dim3(NT), 0, sg.stream, span.a, span.b, 0, b.d_probs, b.d_feat,   \
-                          b.d_mask, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels, b.start_label,      \
-                          b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter,          \
+                          b.d_mask, b.d_mask4, b.d_cent, head_cur, b.d_labels, b.d_acc, RQ, accumulate, store_labels, b.start_label,      \
+                          (float)b.fscale, fp.bin_stamp, fp.tile_lp, fp.cache_k, fp.cache_q, sweep_id, use_cache, px_counter,          \
                           b.d_tile_prob, sg.tile1, orphan_flag, tpp, b.d_fbox, sg.tile0, b.C, b.d_tl_k, b.d_tl_fp, b.d_tl_meta, b.d_tl_req)
     // channels that exist: C of the CP = 4 * ceil(C / 4) the planes and records hold.  The two kernels that run 9 of every 10
     // sweeps come in a variant per padding (slic_assign_body: NCH); the others treat the padded channels like real ones.
@@ -1351,6 +1373,24 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
 #undef LAUNCH_COLLB_
 #undef LAUNCH_MAIN_
 #undef LAUNCH_K_
+}
+
+// d_mask -> d_mask4 (slic.hpp): thread (q, x) packs the mask bytes of the rows 4q .. 4q+3 at column x into one dword.  Once per
+// batch, 2 bytes of traffic per pixel; every sweep then reads a lane's strip with one load instead of four.
+__global__ __launch_bounds__(256) void mask_pack4_kernel(const SlicProblem *__restrict__ probs, const uint8_t *__restrict__ mask,
+                                                         unsigned *__restrict__ mask4) {
+    const SlicProblem P = probs[blockIdx.y];
+    const int nq = (P.H + 3) >> 2;
+    for (int q = blockIdx.x; q < nq; q += gridDim.x)
+        for (int x = threadIdx.x; x < P.W; x += 256) {
+            unsigned w = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = 4 * q + j;
+                if (y < P.H) w |= (unsigned)(mask[P.pix_off + (long long)y * P.W + x] != 0) << (8 * j);
+            }
+            mask4[(long long)P.m4_off + (long long)q * P.W + x] = w;
+        }
 }
 
 __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
@@ -1407,6 +1447,13 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     }
     int maxh_z = 1;
     for (auto &P : b.probs) if (P.H > maxh_z) maxh_z = P.H;
+    if (b.masked && b.d_mask) {   // the packed mask of the sweeps (problems whose mask hides nothing never read it)
+        b.d_mask4 = A.get<unsigned>((size_t)b.total_m4);
+        if (!b.d_mask4) return OBIA_E_NOMEM;
+        int gq = (maxh_z + 3) / 4;
+        if (gq > 16384) gq = 16384;
+        hipLaunchKernelGGL(mask_pack4_kernel, dim3(gq, b.nprob), dim3(256), 0, ctx->stream, b.d_probs, b.d_mask, b.d_mask4);
+    }
     if (maxh_z > 4096) maxh_z = 4096;
 
     // Groups of problems.  The sweeps of ONE launch end with a tail (the last workgroups run on a half-empty chip), the next

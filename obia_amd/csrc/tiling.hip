@@ -7,8 +7,9 @@
 //   within(tile_polygon)   <=>  every pixel of the segment lies inside the grown window minus the two
 //                               bottom corner squares           (count inside == segment size)
 //   overlaps(tile_polygon) <=>  some but not all of its pixels do
-// (segments are 4-connected pixel sets, tile_polygon is pixel-aligned, rasterize() uses the pixel-centre
-// rule, so the pixel statements are exactly the polygon statements).
+// (segments are 4-connected pixel sets and rasterize() uses the pixel-centre rule; the window is pixel-aligned, the two corner
+// squares are when buffer/2 is a whole number of pixels -- otherwise the cut passes THROUGH pixels, and "inside" means three
+// different things for the three uses of the squares: see TileWin).
 //   pass 1  "black" tiles ((i/T + j/T) even), exact windows          tiling.py:103-153
 //   pass 2  "white" tiles, windows grown by `buffer` and clamped      tiling.py:156-172
 //           segments within the polygon are dropped and re-segmented  tiling.py:220-231
@@ -27,7 +28,14 @@
 
 namespace obia {
 
-struct TileWin { int y0, x0, h, w; long long pix_off; int cly, clx; };   // window, dense offset, corner square (px)
+// window, dense offset, corner squares in pixels.  The squares have side buffer/2 in MAP units (tiling.py:189), i.e. a = buffer/2/pixel
+// pixels, which need not be whole; three pixel counts follow from the reference's three uses of the square (per axis):
+//   cl*     pixels whose CENTRE lies inside: what rasterize() burns into the mask (all_touched=False)        tiling.py:245-255
+//   cl*_in  pixels that lie WHOLLY inside: a segment made of such pixels only has no area in tile_polygon,
+//           it is neither `within` nor `overlaps` (not selected)                                             tiling.py:205-210
+//   cl*_any pixels that meet the square's interior at all: a segment with such a pixel is not `within`       tiling.py:220-231
+// (equal when a is a whole number -- even buffer, pixel size 1 or 0.5 -- which is every case rounds 1-3 tested)
+struct TileWin { int y0, x0, h, w; long long pix_off; int cly, clx; int cly_in, clx_in, cly_any, clx_any; };
 
 // wave-aggregated histogram add: lanes of a wave that hold the same key add once
 __device__ __forceinline__ void wave_hist_add(unsigned *hist, int key, bool active) {
@@ -46,10 +54,17 @@ __device__ __forceinline__ void wave_hist_add(unsigned *hist, int key, bool acti
 __device__ __forceinline__ bool in_corner(const TileWin &t, int y, int x) {
     return (y >= t.h - t.cly) && (x < t.clx || x >= t.w - t.clx);
 }
+__device__ __forceinline__ bool wholly_in_corner(const TileWin &t, int y, int x) {
+    return (y >= t.h - t.cly_in) && (x < t.clx_in || x >= t.w - t.clx_in);
+}
+__device__ __forceinline__ bool meets_corner(const TileWin &t, int y, int x) {
+    return (y >= t.h - t.cly_any) && (x < t.clx_any || x >= t.w - t.clx_any);
+}
 
-// white tiles, step 1: pixels of every existing segment that lie inside the tile polygon
-// tile_any[tile] = 1 when some existing segment has a pixel inside the polygon: `not intersecting_black_segments.empty or not
-// intersecting_white_segments.empty` (tiling.py:205-212)
+// white tiles, step 1: inside[g] = pixels of every existing segment that lie in the window and do not meet a corner square
+// (inside[g] == seg_size[g]  <=>  the segment is `within` tile_polygon)
+// tile_any[tile] = 1 when some existing segment has area inside the polygon -- a pixel in the window that is not wholly inside a
+// corner square: `not intersecting_black_segments.empty or not intersecting_white_segments.empty` (tiling.py:205-212)
 __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ G,
                                                                 int Wr, unsigned *__restrict__ inside, int *__restrict__ tile_any) {
     const TileWin t = wins[blockIdx.y];
@@ -62,8 +77,11 @@ __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *_
             for (int u = 0; u < 4; ++u) {
                 const int x = x0 + 256 * u + threadIdx.x;
                 g[u] = 0;
-                if (x < t.w && !in_corner(t, y, x)) g[u] = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
-                seen |= g[u] > 0;
+                if (x < t.w && !wholly_in_corner(t, y, x)) {
+                    g[u] = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
+                    seen |= g[u] > 0;
+                    if (meets_corner(t, y, x)) g[u] = 0;   // (a pixel the cut passes through: selected, but not counted as inside)
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -127,7 +145,7 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
             if (x < t.w) {
                 const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
                 mv[u] = inmask ? (inmask[gp] != 0) : 1;
-                if (white && !in_corner(t, y, x)) gv[u] = G[gp];
+                if (white && !in_corner(t, y, x)) gv[u] = G[gp];   // (outside the burned square => not wholly inside it: the segment is selected)
             }
         }
 #pragma unroll
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
 // a lane walks one column (runs of equal label down the column are counted in a register), run totals go to a 128-slot
 // LDS table keyed by label, and the table is flushed with one global atomic per (block, label).
 constexpr int TS_SLOTS = 128;
-__global__ __launch_bounds__(64) void tile_scatter_kernel(const TileWin *__restrict__ wins, const int32_t *__restrict__ lab,
+__global__ __launch_bounds__(64) void tile_scatter_kernel(const TileWin *__restrict__ wins, const CcResolve R,
                                                           int32_t *__restrict__ G, int Wr, int id_base,
                                                           unsigned *__restrict__ seg_size) {
     __shared__ int s_key[TS_SLOTS];
@@ -181,7 +199,8 @@ __global__ __launch_bounds__(64) void tile_scatter_kernel(const TileWin *__restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int y = y0 + j;
-            l[j] = (col_ok && y < y_hi) ? lab[t.pix_off + (long long)y * t.w + x] : 0;
+            // (the label of the pixel's component, resolved here: the connectivity pass hands over its tables instead of a label map)
+            l[j] = (col_ok && y < y_hi) ? cc_resolve_label(R, t.pix_off + (long long)y * t.w + x) : 0;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -286,7 +305,7 @@ struct TileState {
     int *newid;
     long long *d_total;
     int id_cap, next_id;   // provisional ids 1..next_id-1
-    int clx, cly;          // corner square (pixels)
+    int clx, cly, clx_in, cly_in, clx_any, cly_any;   // corner squares in pixels (see TileWin)
     obia_tiling_params tp;
     obia_slic_params sp;
     // features of ALL white tiles, prepared in one batch (they depend on the raster only): windows in processing order,
@@ -438,6 +457,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     OBIA_TRY(slic_run_sweeps(ctx, b));
     debug_sync(ctx, "tiler: sweeps");
     int n_new = 0;
+    CcResolve resolve{};
     if (S.sp.enforce_connectivity) {
         std::vector<CcProblem> cps(np);
         for (int p = 0; p < np; ++p) {
@@ -447,7 +467,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
             const int mx = mxd >= 2147483647.0 ? 2147483647 : (int)mxd;
             cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp.min_size_factor * segment_size), mx > 0 ? mx : 1};
         }
-        OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new));
+        OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new, &resolve));
         debug_sync(ctx, "tiler: connectivity");
     } else {
         set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)");
@@ -457,7 +477,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     if (n_new > 0) {
         int sblocks = 1;
         for (auto &t : wins) sblocks = std::max(sblocks, cdiv(t.w, 64) * cdiv(t.h, 64));
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3(sblocks, np), dim3(64), 0, ctx->stream, d_wins, d_final, S.G, S.W,
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(sblocks, np), dim3(64), 0, ctx->stream, d_wins, resolve, S.G, S.W,
                            S.next_id - 1, S.seg_size);
         OBIA_HIP_TRY(hipMemsetAsync(S.alive + S.next_id, 1, (size_t)n_new, ctx->stream));
         S.next_id += n_new;
@@ -515,13 +535,23 @@ static int tiler_init(obia_ctx *ctx, TileState &S, const float *img, const uint8
     OBIA_HIP_TRY(hipMemsetAsync(S.alive, 0, (size_t)cap, ctx->stream));
     // corner squares: side buffer/2 in MAP units (tiling.py:189), i.e. buffer/2/pixel_size pixels; a pixel is
     // inside when its centre is (rasterize default all_touched=False)
-    S.clx = S.cly = 0;
+    S.clx = S.cly = S.clx_in = S.cly_in = S.clx_any = S.cly_any = 0;
     if (B > 0) {
         const double cl = (double)B / 2.0;
-        S.clx = (int)std::ceil(cl / (tp->pixel_width > 0 ? tp->pixel_width : 1.0) - 0.5);
-        S.cly = (int)std::ceil(cl / (tp->pixel_height > 0 ? tp->pixel_height : 1.0) - 0.5);
-        if (S.clx < 0) S.clx = 0;
-        if (S.cly < 0) S.cly = 0;
+        // pixel k of an axis (counted from the square's outer edge) spans [k * px, (k + 1) * px) map units; the three counts are the
+        // numbers of k with  centre (k + 0.5) * px < cl,  far edge (k + 1) * px <= cl,  near edge k * px < cl  -- evaluated as written,
+        // in doubles, so that a quotient like 3.5 / 0.7 landing a hair beside a whole number cannot move a count
+        auto count = [](double px, double cl, int kind) {
+            if (!(px > 0.0)) px = 1.0;
+            long long k = (long long)std::floor(cl / px) + 2;
+            if (k < 0) k = 0;
+            auto holds = [&](long long i) { return kind == 0 ? (i + 0.5) * px < cl : (kind == 1 ? (i + 1.0) * px <= cl : i * px < cl); };
+            while (k > 0 && !holds(k - 1)) --k;     // k = number of pixels 0 .. k-1 for which the statement holds (it is monotone in k)
+            return (int)std::min<long long>(k, 0x3fffffff);
+        };
+        S.clx = count(tp->pixel_width, cl, 0);  S.cly = count(tp->pixel_height, cl, 0);
+        S.clx_in = count(tp->pixel_width, cl, 1);  S.cly_in = count(tp->pixel_height, cl, 1);
+        S.clx_any = count(tp->pixel_width, cl, 2);  S.cly_any = count(tp->pixel_height, cl, 2);
     }
     return OBIA_OK;
 }
@@ -531,7 +561,9 @@ static TileWin white_window(const TileState &S, int tj, int ti) {
     const int T = S.tp.tile_size, B = S.tp.buffer;
     const int y0 = std::max(0, tj * T - B), y1 = std::min(S.Hg, tj * T + T + B);
     const int x0 = std::max(0, ti * T - B), x1 = std::min(S.W, ti * T + T + B);
-    return TileWin{y0 - S.row0, x0, y1 - y0, x1 - x0, 0, std::min(S.cly, y1 - y0), std::min(S.clx, x1 - x0)};
+    const int h = y1 - y0, w = x1 - x0;
+    return TileWin{y0 - S.row0, x0, h, w, 0, std::min(S.cly, h), std::min(S.clx, w), std::min(S.cly_in, h), std::min(S.clx_in, w),
+                   std::min(S.cly_any, h), std::min(S.clx_any, w)};
 }
 
 // The feature pass of ALL white tiles runs as ONE batch before the white rows (it depends on the raster only), in the
@@ -650,7 +682,7 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
             const bool is_white = (ti + tj) % 2 != 0;
             if (is_white != white) continue;
             if (!white) {
-                TileWin t{tj * T - S.row0, ti * T, std::min(T, S.Hg - tj * T), std::min(T, S.W - ti * T), 0, 0, 0};
+                TileWin t{tj * T - S.row0, ti * T, std::min(T, S.Hg - tj * T), std::min(T, S.W - ti * T), 0, 0, 0, 0, 0, 0, 0};
                 if (t.h > 0 && t.w > 0) wins.push_back(t);
             } else {
                 const TileWin t = white_window(S, tj, ti);

@@ -205,6 +205,31 @@ class ThreadComm:
         return out
 
 
+class _PhaseClock:
+    """Host clock per phase of one sharded call (halo, black, import, class0, class1, export, relabel), opt-in (``profile=True``):
+    the device is synchronised at every phase boundary, so the phases add up to the call and a slow rank's line says where it
+    was slow.  Off by default: the boundaries are otherwise crossed without a device synchronisation."""
+
+    def __init__(self, on, dev):
+        self.on, self.dev, self.ms, self._t = bool(on), dev, {}, None
+
+    def _now(self):
+        if getattr(self.dev, "type", "cpu") == "cuda":
+            torch.cuda.synchronize(self.dev)
+        import time
+        return time.perf_counter()
+
+    def start(self):
+        if self.on:
+            self._t = self._now()
+
+    def lap(self, name):
+        if self.on:
+            t = self._now()
+            self.ms[name] = self.ms.get(name, 0.0) + (t - self._t) * 1e3
+            self._t = t
+
+
 class ShardedTiler:
     """One rank of the sharded driver.  ``slab`` / ``mask_slab``: this rank's rows (whole tile rows).
 
@@ -223,6 +248,8 @@ class ShardedTiler:
     def __init__(self, slab, mask_slab, global_rows, tile_rows_per_rank, tile_size, buffer, crown_radius=5,
                  pixel_size=(1.0, 1.0), engine_factory=None, group=None, ctx=None, ext_image=None, ext_mask=None, comm=None,
                  **slic_kwargs):
+        self.clock = _PhaseClock(slic_kwargs.pop("profile", False), slab.device)
+        self.clock.start()
         self.comm = comm if comm is not None else TorchComm(group)
         self.rank, self.world = self.comm.rank, self.comm.world
         if self.world > 127:
@@ -284,6 +311,7 @@ class ShardedTiler:
         self.f_batches = []   # (owner rank, first local id, count): contiguous ranges of imported ids
         self.stats = {"imports": 0, "foreign_ids": 0, "kills_sent_up": 0, "kills_sent_down": 0}   # host-side counters (tests)
         self._check_ids()
+        self.clock.lap("halo_ms")        # halo rows of image and mask + the engine's set-up
 
     # ---- communication helpers ---------------------------------------------------------------------------------
     def _to_wire(self, t):
@@ -441,10 +469,12 @@ class ShardedTiler:
             self.G[top + Hs:] = self._ids_of(rbuf["down"].to(self.G.device), (self.rank + 1,)).to(self.G.dtype)
         if au or ad:
             self._refresh_foreign_sizes()
+        self.clock.lap("import_ms")      # boundary rows in: exchange + codes -> local ids + sizes of the imported segments
         # 2. the pass itself: every tile row of this parity in my slab
         tr_lo = self.rank * self.R
         self.engine.run(True, tr_lo, tr_lo + (-(-Hs // self.T)), cls)
         self._check_ids()
+        self.clock.lap("class%d_ms" % cls)
         # 3. active sides send the halo rows back, followed by hb rows that list the neighbour's segments they dropped
         #    ([count, code, code, ...]: every imported segment has a pixel in the hb rows, so the list always fits);
         #    the owner overwrites its boundary rows and clears those segments
@@ -468,6 +498,7 @@ class ShardedTiler:
             buf = rbuf["down"].to(self.G.device)
             self.G[top + Hs - hb:top + Hs] = self._ids_of(buf[:hb], (self.rank + 1,)).to(self.G.dtype)
             self._apply_kills(buf[hb:])
+        self.clock.lap("export_ms")      # halo rows back to their owner + the segments dropped there
 
     def _rows_with_kills(self, rows, owner_rank, stat):
         """int32 codes of `rows` followed by as many rows again holding [count, codes of owner_rank's segments that I dropped
@@ -514,11 +545,14 @@ class ShardedTiler:
     def _run(self):
         tr_lo = self.rank * self.R
         ntr = -(-self.Hs // self.T)
+        self.clock.start()
         self.engine.run(False, tr_lo, tr_lo + ntr, -1)          # pass 1: black tiles, no communication
         self._check_ids()
+        self.clock.lap("black_ms")
         self._white_class(0)
         self._white_class(1)
         labels, n = self._global_labels()
+        self.clock.lap("relabel_ms")     # global ids: the one all_gather, the neighbours' numbering, the look-up
         return labels, n
 
     def _number_segments(self):

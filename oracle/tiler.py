@@ -38,9 +38,26 @@ class OracleTiler:
         self.alive = {}
         self.next_id = 1
         self.untouched_white_tiles = []  # white tiles (tj, ti) that took the else branch of tiling.py:212 (tests)
+        # corner squares of side buffer/2 MAP units (tiling.py:189-203) in pixels, per axis -- the side need not be a whole number of
+        # pixels, and the reference uses the squares in three ways (pixel k counted from the square's outer edge spans
+        # [k * px, (k + 1) * px)):
+        #   cl*     centre inside,        (k + 0.5) * px <  cl : what rasterize() burns (all_touched=False, tiling.py:245-255)
+        #   cl*_in  wholly inside,        (k + 1)   * px <= cl : a segment of such pixels only has no area in tile_polygon -- neither
+        #                                                        `within` nor `overlaps`, it is not selected (tiling.py:205-210)
+        #   cl*_any meets the interior,    k        * px <  cl : a segment with such a pixel is not `within` (tiling.py:220-231)
         cl = self.B / 2.0
-        self.clx = max(0, int(math.ceil(cl / self.pw - 0.5))) if self.B > 0 else 0
-        self.cly = max(0, int(math.ceil(cl / self.ph - 0.5))) if self.B > 0 else 0
+
+        def count(px, kind):
+            if self.B <= 0:
+                return 0
+            holds = {0: lambda i: (i + 0.5) * px < cl, 1: lambda i: (i + 1.0) * px <= cl, 2: lambda i: i * px < cl}[kind]
+            k = max(0, int(math.floor(cl / px)) + 2)
+            while k > 0 and not holds(k - 1):
+                k -= 1
+            return k
+        self.clx, self.cly = count(self.pw, 0), count(self.ph, 0)
+        self.clx_in, self.cly_in = count(self.pw, 1), count(self.ph, 1)
+        self.clx_any, self.cly_any = count(self.pw, 2), count(self.ph, 2)
 
     def set_segments(self, first_id, sizes):
         for i, s in enumerate(sizes):
@@ -89,18 +106,24 @@ class OracleTiler:
                 y0, y1 = gy0 - self.row0, gy1 - self.row0
                 assert 0 <= y0 and y1 <= self.H, "halo too small"
                 h, w = y1 - y0, x1 - x0
-                corner = np.zeros((h, w), bool)
-                cy, cx = min(self.cly, h), min(self.clx, w)
-                if cy > 0 and cx > 0:
-                    corner[h - cy:, :cx] = True
-                    corner[h - cy:, w - cx:] = True
+                def squares(cy, cx):
+                    m = np.zeros((h, w), bool)
+                    cy, cx = min(cy, h), min(cx, w)
+                    if cy > 0 and cx > 0:
+                        m[h - cy:, :cx] = True
+                        m[h - cy:, w - cx:] = True
+                    return m
+                corner = squares(self.cly, self.clx)            # burned into the mask
+                corner_in = squares(self.cly_in, self.clx_in)   # pixels with no area in tile_polygon
+                corner_any = squares(self.cly_any, self.clx_any)  # pixels the squares reach at all
                 sub = self.G[y0:y1, x0:x1]
                 tmask = self.inmask[y0:y1, x0:x1].copy()
-                inside = sub[~corner]                          # tile_polygon = window minus the corner squares (:187-203)
-                ids, cnt = np.unique(inside[inside > 0], return_counts=True)
+                area = sub[~corner_in]                          # tile_polygon = window minus the corner squares (:187-203)
+                ids = np.unique(area[area > 0])                 # segments with area in the polygon: within or overlaps (:205-210)
+                clear = sub[~corner_any]
                 if len(ids):                                   # some segment is within / overlaps the polygon (:205-212)
-                    for g, c in zip(ids, cnt):
-                        if c == self.sizes[g]:                 # within(tile_polygon): dropped (:220-231)
+                    for g in ids:
+                        if int((clear == g).sum()) == self.sizes[g]:   # within(tile_polygon): dropped (:220-231)
                             sub[sub == g] = 0
                             self.alive[g] = False
                     tmask[sub > 0] = False                     # overlaps: kept and masked out (:213-218, :233-244, :257-258)

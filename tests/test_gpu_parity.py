@@ -3,7 +3,9 @@
 
 Stated tolerances (north_star: "label maps within a stated adjusted-Rand / boundary-recall tolerance,
 per-segment band statistics within 1e-5 relative"):
-  * pre-connectivity labels: <= 1e-4 of pixels differ from the oracle on non-Lab inputs (the only
+  * labels vs the scikit-image goldens: BIT-EXACT before and after connectivity for every case that is not on the
+    explicit allow-list NOT_BIT_EXACT below (one Lab case, a handful of pixels);
+  * pre-connectivity labels vs the ORACLE on random inputs: <= 1e-4 of pixels differ on non-Lab inputs (the only
     source of difference is the rounding of centroid colour means: the reference accumulates them
     sequentially in float32, the HIP path in exact 64-bit fixed point), <= 5e-4 on 3-band Lab inputs
     (device powf/cbrtf vs libm);
@@ -59,6 +61,17 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a)).cuda()
 
 
+# Every scikit-image golden of the grid path is reproduced BIT FOR BIT, before and after connectivity -- with the exceptions listed
+# here, each with the largest number of differing pixels accepted (before, after connectivity).  Measured by
+# tools/golden_exactness.py (round 4: c1_512x512x3 6 / 3 px of 262 144; every other case 0 / 0).  A case that is not listed must
+# be array_equal: a regression from 0 differing pixels to "within the stated tolerance" fails (Weak 2).
+NOT_BIT_EXACT = {
+    # sRGB -> Lab on the device: powf / cbrtf of the HIP runtime against the libm scikit-image was built on (last-bit differences in
+    # a few features move a handful of near-tie pixels).  The other Lab golden, quickstart_128x128x3, is exact.
+    "c1_512x512x3": (8, 5),
+}
+
+
 @pytest.mark.parametrize("name", UNMASKED)
 def test_slic_pre_connectivity_vs_golden(amd, name):
     from obia_amd.segmentation import slic
@@ -67,10 +80,12 @@ def test_slic_pre_connectivity_vs_golden(amd, name):
     pre = slic(raw, enforce_connectivity=False, _normalize_bands=True, _stage="pre", **{k: v for k, v in kwargs_of(params).items()
                                                                                        if k not in ("min_size_factor", "max_size_factor")})
     pre = pre.cpu().numpy()
-    lab3 = z["raw"].shape[2] == 3 and params.get("convert2lab", None) is not False
-    tol = 5e-4 if lab3 else 1e-4
-    dis = label_disagreement(pre, z["labels_pre"])
-    assert dis <= tol, f"{name}: {dis:.2e} of pixels differ before connectivity"
+    nd = int((pre != z["labels_pre"]).sum())
+    if name in NOT_BIT_EXACT:
+        assert nd <= NOT_BIT_EXACT[name][0], f"{name}: {nd} pixels differ before connectivity (allow-list: {NOT_BIT_EXACT[name][0]})"
+        assert label_disagreement(pre, z["labels_pre"]) <= 5e-4    # the stated tolerance of the Lab cases
+    else:
+        assert nd == 0, f"{name}: {nd} pixels differ before connectivity (the case is not on the allow-list: it must be bit-exact)"
 
 
 @pytest.mark.parametrize("name", UNMASKED)
@@ -82,10 +97,13 @@ def test_slic_final_vs_golden(amd, name):
     lab = slic(raw, _normalize_bands=True, **kwargs_of(params))
     gold = z["labels"]
     assert lab.dtype == np.int64 and lab.shape == gold.shape
-    if "sizefac" in name:
-        # max_size_factor 1.2 makes the reference cut most components at max_size (capped BFS, cc_split_kernel): the
-        # pre-connectivity labels are bit-exact for this case, so the cut pieces must be too
-        assert np.array_equal(lab, gold), f"{(lab != gold).mean():.3%} of pixels differ after the max_size cut"
+    # bit-exact unless the case is on the allow-list above ("sizefac": max_size_factor 1.2 makes the reference cut most components
+    # at max_size -- capped BFS, cc_split_kernel -- and the cut pieces are exact too)
+    nd = int((lab != gold).sum())
+    if name in NOT_BIT_EXACT:
+        assert nd <= NOT_BIT_EXACT[name][1], f"{name}: {nd} pixels differ after connectivity (allow-list: {NOT_BIT_EXACT[name][1]})"
+    else:
+        assert nd == 0, f"{name}: {nd} pixels differ after connectivity (the case is not on the allow-list: it must be bit-exact)"
     ari = adjusted_rand_index(lab, gold)
     rec, prec = boundary_recall_precision(gold, lab)
     n_g, n_l = len(np.unique(gold)), len(np.unique(lab))

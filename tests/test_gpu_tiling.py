@@ -116,3 +116,41 @@ def test_tiled_errors():
         create_tiled_segments(img, method="quickshift")
     with pytest.raises(TypeError):
         create_tiled_segments(img, bogus=1)
+
+
+def test_corner_squares_that_cut_through_pixels_hip_vs_known_answers():
+    """The same three segments as tests/test_oracle_known_answers.py::test_tiler_corner_squares_that_cut_through_pixels, through the
+    tiler session of the HIP library (obia_tiler_*): buffer 5 at pixel size 1 -> corner length 2.5 pixels."""
+    from obia_amd.distributed import HipTilerEngine
+    rs = np.random.RandomState(3)
+    img = torch.as_tensor(rs.rand(40, 40, 2).astype(np.float32)).cuda()
+    mask = torch.ones((40, 40), dtype=torch.uint8, device="cuda")
+    e = HipTilerEngine(img, mask, 40, 0, 20, 5, 2.0, (1.0, 1.0), {}, 8)
+    try:
+        for g, (y, x) in enumerate([(24, 17), (24, 15), (10, 25)], start=1):
+            e.G[y, x] = g
+        e.set_segments(1, torch.tensor([1, 1, 1]))
+        e.run(True, 0, 1)
+        alive = e.get_alive(4).cpu().numpy()
+        G = e.G.cpu().numpy()
+        assert alive[1] == 1 and G[24, 17] == 1          # the cut passes through it: overlaps -> kept and masked
+        assert alive[2] == 1 and G[24, 15] == 2          # wholly inside the square: not selected
+        assert alive[3] == 0 and G[10, 25] > 3           # within: dropped, re-segmented
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("buffer,pixel", [(9, (1.0, 1.0)), (15, (1.0, 1.0)), (12, (0.3, 0.3)), (13, (0.7, 0.5)), (25, (2.0, 3.0))])
+def test_tiler_with_a_corner_length_that_is_not_a_whole_number_of_pixels(oracle, buffer, pixel):
+    """odd buffers and pixel sizes that do not divide buffer / 2 (Weak 3): HIP tile loops vs oracle/tiler.py"""
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    rs = np.random.RandomState(buffer)
+    H, W = 230, 260
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.stack([350 * np.sin(xx / (9 + 3 * c)) * np.cos(yy / (12 + 2 * c)) + 900 + 60 * c + rs.normal(0, 22, (H, W)) for c in range(4)], -1).astype(np.float32)
+    mask = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (0.47 * W) ** 2)
+    kw = dict(tile_size=70, buffer=buffer, crown_radius=3.0 * max(pixel), pixel_size=pixel, compactness=10.0)
+    ref, n_ref = tiler.create_tiled_segments(img, mask, **kw)
+    lab, n = create_tiled_segments(torch.as_tensor(img).cuda(), input_mask=mask, **kw)
+    assert n == n_ref and np.array_equal(lab.cpu().numpy(), ref)

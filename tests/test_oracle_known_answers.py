@@ -126,3 +126,29 @@ def test_edge_raster_known_answers():
     v = np.arange(101, dtype=np.float64)
     out = percentile_stretch(v)
     assert out[0] == 0 and out[2] == 0 and out[100] == 1 and out[98] == 1 and abs(out[50] - 0.5) < 1e-12
+
+
+def test_tiler_corner_squares_that_cut_through_pixels():
+    """tiling.py:189-231 with a corner length that is not a whole number of pixels (odd buffer, or a pixel size that does not divide
+    buffer / 2): rasterize() burns the pixels whose CENTRE is inside the square, a segment whose pixels lie WHOLLY inside has no area
+    in tile_polygon (not selected), and a segment with a pixel the square reaches at all is not `within` (Weak 3).
+    Known answers for the three counts, and the segment the cut passes through: `overlaps` -> kept and masked, not dropped."""
+    from oracle.tiler import OracleTiler
+    rs = np.random.RandomState(3)
+    img = rs.rand(40, 40, 2).astype(np.float32)
+    t = OracleTiler(img, None, 40, 0, tile_size=20, buffer=5, crown_radius=2, pixel_size=(1.0, 1.0))
+    assert (t.clx, t.clx_in, t.clx_any) == (2, 2, 3) and (t.cly, t.cly_in, t.cly_any) == (2, 2, 3)        # a = 2.5
+    u = OracleTiler(img, None, 40, 0, tile_size=20, buffer=5, crown_radius=2, pixel_size=(0.7, 0.5))
+    assert (u.clx, u.clx_in, u.clx_any) == (4, 3, 4) and (u.cly, u.cly_in, u.cly_any) == (5, 5, 5)        # a = 3.571..., 5
+    v = OracleTiler(img, None, 40, 0, tile_size=20, buffer=12, crown_radius=2, pixel_size=(0.5, 1.0))
+    assert (v.clx, v.clx_in, v.clx_any) == (12, 12, 12) and (v.cly, v.cly_in, v.cly_any) == (6, 6, 6)     # whole numbers: one count
+    # white tile (0, 1): window rows [0, 25), columns [15, 40).  Segment 1 = the one pixel at window (24, 2): the square (side 2.5)
+    # covers half of it -- it has area in the polygon and is not within it: overlaps.  Segment 2 = window (24, 0): wholly inside
+    # the square -- not selected, but under the burned corner.  Segment 3 = window (10, 10): within -> dropped, re-segmented.
+    for g, (y, x) in enumerate([(24, 15 + 2), (24, 15 + 0), (10, 15 + 10)], start=1):
+        t.G[y, x] = g
+    t.set_segments(1, [1, 1, 1])
+    t.run(True, 0, 1)
+    assert t.alive[1] and t.G[24, 17] == 1          # kept (and masked: no new segment took the pixel)
+    assert t.alive[2] and t.G[24, 15] == 2          # untouched
+    assert not t.alive[3] and t.G[10, 25] > 3       # dropped and re-segmented
