@@ -84,10 +84,13 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
+TRAFFIC_FILE = "r04_traffic.json"   # profiles/: the newest PMC traffic measurement (tools/traffic_json.py)
+
+
 def traffic_fields(args, C, world):
-    """roofline.traffic from profiles/r03_traffic.json (written by tools/traffic_json.py from two rocprofv3 --pmc passes of
+    """roofline.traffic from profiles/<TRAFFIC_FILE> (written by tools/traffic_json.py from two rocprofv3 --pmc passes of
     this workload).  null unless the file was measured on exactly these kernel sources and this workload."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     none = {"traffic": None, "traffic_source": None}
     try:
         with open(path) as fh:
@@ -99,12 +102,12 @@ def traffic_fields(args, C, world):
     same_wl = (world == 1 and args.config == "c3" and wl.get("size") == args.size and wl.get("tile") == args.tile
                and wl.get("buffer") == args.buffer and wl.get("bands") == C and abs(wl.get("compactness", -1) - args.compactness) < 1e-12)
     if not (same_src and same_wl):
-        return dict(none, traffic_source=f"profiles/r03_traffic.json is for other {'sources' if not same_src else 'workload'} "
+        return dict(none, traffic_source=f"profiles/{TRAFFIC_FILE} is for other {'sources' if not same_src else 'workload'} "
                                          f"(measured at commit {t.get('commit')}): not reported")
     k = t["kernels"]["slic_assign_colour"]
     return {"traffic": int(round(k["bytes_per_launch"])),
-            "traffic_source": f"profiles/r03_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per launch, measured at commit {t.get('commit')} "
-                              f"on the same kernel sources ({k['bytes_per_pixel']:.1f} B/pixel vs 36 algorithmic)"}
+            "traffic_source": f"profiles/{TRAFFIC_FILE}: PMC FETCH_SIZE x2 + WRITE_SIZE per launch, measured at commit {t.get('commit')} "
+                              f"on the same kernel sources ({k['bytes_per_pixel']:.1f} B/pixel vs 32.4 algorithmic)"}
 
 
 def cpu_baseline(C, tile, buffer_, crown_radius, pixel, compactness):
@@ -483,7 +486,34 @@ def main():
         torch.cuda.empty_cache()
         return out9
 
+    def next_rows_leg():
+        """SURVEY 8f's rows that share the headline's inputs, on the headline raster and its label map: skewness / kurtosis (f2, the
+        second pass over (labels, raster) of zonal_stats(moments=True): segment_statistics.py:173-175) and the GLCM texture statistics
+        (f3, segment_statistics.py:179-298).  Times are whole calls (host clock around a synchronised call, median of three);
+        bytes = the raster and the labels read once by the pass: 4C + 4 per pixel."""
+        if world != 1 or args.no_side:
+            return None
+        from obia_amd.statistics import texture_stats
+        lab_n, n_n = create_tiled_segments(img, input_mask=mask, **kw)
+
+        def med(fn):
+            fn(); torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t1 = time.time(); fn(); torch.cuda.synchronize(); ts.append(time.time() - t1)
+            return sorted(ts)[1]
+        t_stats = med(lambda: zonal_stats(img, lab_n, n_labels=n_n, ctx=ctx))
+        t_both = med(lambda: zonal_stats(img, lab_n, n_labels=n_n, ctx=ctx, moments=True))
+        t_tex1 = med(lambda: texture_stats(img, lab_n, bands=[0], n_labels=n_n, ctx=ctx))
+        gb = float(H) * W * (4 * C + 4) / 1e9
+        mom = max(t_both - t_stats, 1e-9)
+        return {"segments": int(n_n), "statistics_ms": round(t_stats * 1e3, 3), "statistics_GBps": round(gb / t_stats, 1),
+                "moments_ms": round(mom * 1e3, 3), "moments_GBps": round(gb / mom, 1), "moments_frac_of_hbm_peak": round(gb / mom / HBM_PEAK_GBS, 3),
+                "texture_one_band_ms": round(t_tex1 * 1e3, 3), "texture_one_band_GBps": round(float(H) * W * 8 / 1e9 / t_tex1, 1),
+                "note": "moments = zonal_stats(moments=True) minus zonal_stats(): the skewness / kurtosis pass alone; texture reads one band and the labels (8 B per pixel)"}
+
     c025_leg = compactness_leg(0.25) if abs(args.compactness - 0.25) > 1e-9 else None
+    nr_leg = next_rows_leg()
     b9_leg = bands_leg(9)
     qs_leg = quickshift_leg()
     c4_whole = c4_leg()
@@ -537,6 +567,7 @@ def main():
         out["quickshift"] = qs_leg
         out["c4_whole_on_one_gpu"] = c4_whole
         out["bands_9"] = b9_leg
+        out["next_rows"] = nr_leg
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -200,54 +200,34 @@ __global__ __launch_bounds__(256) void cc_seam_kernel(const CcProblem *__restric
     }
 }
 
-// flatten + component sizes (wave-aggregated: lanes of a wave that share a root add once)
-__global__ __launch_bounds__(256) void cc_flatten_kernel(int *__restrict__ parent, int *__restrict__ size, long long n,
-                                                         unsigned long long *__restrict__ rootbits,
-                                                         const unsigned long long *__restrict__ lrbits) {
-    // four pixels per lane, chased in lockstep: the dependent parent loads of the four chains are in flight together
-    constexpr int FU = 4;
-    for (long long i0 = (long long)blockIdx.x * blockDim.x * FU; i0 < n; i0 += (long long)gridDim.x * blockDim.x * FU) {
-        long long idx[FU];
-        int r[FU];
-        bool open[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            idx[u] = i0 + (long long)u * blockDim.x + threadIdx.x;
-            r[u] = idx[u] < n ? parent[idx[u]] : -1;
-            open[u] = r[u] >= 0 && r[u] != (int)idx[u];     // a pixel that is its own parent is a root already
-        }
-        for (;;) {
-            int q[FU];
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < FU; ++u) if (open[u]) q[u] = ld_agent(&parent[r[u]]);
-#pragma unroll
-            for (int u = 0; u < FU; ++u)
-                if (open[u]) {
-                    if (q[u] == r[u]) open[u] = false;
-                    else { r[u] = q[u]; any = true; }
-                }
-            if (!any) break;
-        }
-        // one bit per pixel: "is a root".  The ranking passes read this map (1/8 byte per pixel) and the sizes of the roots instead
-        // of parent[] and size[] of every pixel (a wave's 64 pixels are consecutive and 64-aligned: one word per wave and u)
-        unsigned long long lrw[FU];   // the local-root flags of the wave's 64 pixels (cc_tile_kernel)
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const unsigned long long bal = __ballot(r[u] >= 0 && r[u] == (int)idx[u]);
-            const long long first = idx[u] - (threadIdx.x & 63);
-            if ((threadIdx.x & 63) == 0 && first < n) rootbits[first >> 6] = bal;
-            lrw[u] = first < n ? lrbits[first >> 6] : 0ull;   // (wave-uniform address)
-        }
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            if (r[u] < 0) continue;
-            parent[idx[u]] = r[u];   // roots only move to smaller indices, final value is the root
-            // size[] holds the pixel count of every tile-local component at its local root (flagged in lrbits): a local root that is
-            // not the global root adds its count to the global root (which keeps its own); size[] of other pixels is never read
-            if (((lrw[u] >> (threadIdx.x & 63)) & 1ull) && r[u] != (int)idx[u]) atomicAdd(&size[r[u]], size[idx[u]]);
-        }
+// After the seam unions only the LOCAL ROOTS need to be brought to their final root (round 4): a pixel's parent is its tile-local root
+// (cc_tile_kernel), the unions re-point roots only, so once every local root points straight at the root of its component a pixel's
+// root is parent[parent[pixel]] -- cc_root_of() -- and the pass over all pixels that used to flatten parent[] (4 bytes read and 4
+// written per pixel) is gone.  One wave per 64 words of the local-root bitmap, a lane walks the set bits of its word (a few per
+// tile): the component's pixel count moves to the root, the root bitmap of the ranking passes is the local-root map minus the
+// roots that were linked away.
+__global__ __launch_bounds__(64) void cc_roots_kernel(int *__restrict__ parent, int *__restrict__ size, long long n,
+                                                      const unsigned long long *__restrict__ lrbits,
+                                                      unsigned long long *__restrict__ rootbits) {
+    const long long w = (long long)blockIdx.x * 64 + threadIdx.x, nw = (n + 63) >> 6;
+    if (w >= nw) return;
+    unsigned long long bits = lrbits[w], roots = 0ull;
+    while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int lr = (int)((w << 6) + b);
+        const int r = find_root(parent, lr);
+        if (r == lr) { roots |= 1ull << b; continue; }
+        parent[lr] = r;                       // (roots do not move any more: whoever reads this meanwhile still reaches r)
+        atomicAdd(&size[r], size[lr]);        // size[] of a local root that is not the root is not read afterwards
     }
+    rootbits[w] = roots;
+}
+
+// the root of a pixel's component (-1: masked pixel; other negative values: a pixel of a component that is being cut, cc_split_kernel)
+__device__ __forceinline__ int cc_root_of(const int *__restrict__ parent, long long i) {
+    const int p = parent[i];
+    return p < 0 ? p : ld_agent(&parent[p]);
 }
 
 constexpr int SCAN_NT = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_NT * SCAN_PER;
@@ -290,6 +270,15 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_blocksum_kernel(const CcProbl
 }
 
 // ---- components that reach max_size -----------------------------------------------------------------------------------
+// 0. (this rare path rewrites parents in place: it starts from a fully flattened map -- every thread writes its own entry only, and
+// the entry it reads through, its local root's, already holds the root)
+__global__ __launch_bounds__(256) void cc_flatten_all_kernel(int *__restrict__ parent, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = cc_root_of(parent, i);
+        if (r >= 0) parent[i] = r;
+    }
+}
+
 // 1. every root whose component reaches max_size gets an index b (big_root[b], queue offset); newlab[root] = b
 __global__ __launch_bounds__(256) void cc_big_list_kernel(const CcProblem *__restrict__ probs, int nprob, const int *__restrict__ parent,
                                                           const int *__restrict__ size, long long n, int *__restrict__ newlab,
@@ -313,7 +302,7 @@ __global__ __launch_bounds__(256) void cc_big_mark_kernel(const CcProblem *__res
                                                           int *__restrict__ big_box) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int r = parent[i];
+    const int r = parent[i];   // (flat here: cc_flatten_all_kernel ran first -- this kernel overwrites parents that cc_root_of would read)
     if (r < 0) return;
     const int sz = size[r];
     const CcProblem &P = probs[find_prob(probs, nprob, r)];
@@ -527,7 +516,7 @@ __global__ __launch_bounds__(SCAN_NT) void cc_rank_apply_kernel(const CcProblem 
 __global__ __launch_bounds__(256) void cc_code_kernel(const int *__restrict__ parent, const int *__restrict__ newlab, long long n,
                                                       int *__restrict__ code) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int r = parent[i];
+        const int r = cc_root_of(parent, i);
         int c = -1;
         if (r >= 0) { const int nl = newlab[r]; c = nl >= 0 ? r : nl; }
         code[i] = c;
@@ -569,6 +558,8 @@ __device__ int replay_bfs(const int *__restrict__ code, const int *__restrict__ 
 #pragma unroll
         for (int d = 0; d < 4; ++d) c[d] = code[nb[d]];                 // four loads in flight (CODE = false: `code` is parent[])
         if (!CODE) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) c[d] = c[d] >= 0 ? code[c[d]] : c[d];   // local root -> root (cc_root_of), four in flight again
             int nl[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) nl[d] = newlab[c[d] >= 0 ? c[d] : 0];
@@ -681,7 +672,7 @@ __device__ int small_component_eval(const CcProblem *__restrict__ probs, int npr
             const int xx = x + (d == 0 ? 1 : (d == 1 ? -1 : 0));
             const int yy = y + (d == 2 ? 1 : (d == 3 ? -1 : 0));
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            int c = code[base + yy * W + xx];
+            int c = CODE ? code[base + yy * W + xx] : cc_root_of(code, base + yy * W + xx);
             if (!CODE) c = c < 0 ? -1 : (newlab[c] >= 0 ? c : newlab[c]);
             if (c > -2 || c == mine) continue;
             const int t = -c - 2;
@@ -752,14 +743,15 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     int *block_sums = A.get<int>(3 * (size_t)nb);   // survivors | small components | their pixels (cc_rank_blocksum_kernel)
     unsigned long long *rootbits = A.get<unsigned long long>((size_t)((n + 63) / 64));   // one bit per pixel: root (cc_flatten_kernel)
     if (!rootbits) return OBIA_E_NOMEM;
-    unsigned long long *lrbits = A.get<unsigned long long>((size_t)((n + 63) / 64));     // one bit per pixel: tile-local root (cc_tile_kernel)
-    if (!lrbits) return OBIA_E_NOMEM;
-    OBIA_HIP_TRY(hipMemsetAsync(lrbits, 0, sizeof(unsigned long long) * (size_t)((n + 63) / 64), ctx->stream));
+    // one bit per pixel: tile-local root (cc_tile_kernel); the eight counters sit in front of the map so that ONE fill clears both
+    unsigned long long *lrbits_block = A.get<unsigned long long>((size_t)((n + 63) / 64) + 4);
+    if (!lrbits_block) return OBIA_E_NOMEM;
+    unsigned long long *lrbits = lrbits_block + 4;
     const unsigned long long *rb = rootbits;   // the map the ranking passes read; null once the size cut has changed the roots
-    int *counters = A.get<int>(8);
-    if (!d_probs || !parent || !size || !newlab || !block_sums || !counters) return OBIA_E_NOMEM;
+    int *counters = reinterpret_cast<int *>(lrbits_block);
+    if (!d_probs || !parent || !size || !newlab || !block_sums) return OBIA_E_NOMEM;
     OBIA_TRY(upload_async(ctx, d_probs, probs.data(), sizeof(CcProblem) * np));
-    OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+    OBIA_HIP_TRY(hipMemsetAsync(lrbits_block, 0, sizeof(unsigned long long) * ((size_t)((n + 63) / 64) + 4), ctx->stream));
     int gs = cdiv(n, 256 * 4);
     if (gs > 65535 * 4) gs = 65535 * 4;
     {
@@ -777,8 +769,8 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         hipLaunchKernelGGL(cc_seam_kernel, dim3(sg, np), dim3(256), 0, ctx->stream, d_probs, labels_in, parent, mask_label);
     }
     debug_sync(ctx, "cc: tile + seam");
-    hipLaunchKernelGGL(cc_flatten_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, size, n, rootbits, lrbits);
-    debug_sync(ctx, "cc: flatten");
+    hipLaunchKernelGGL(cc_roots_kernel, dim3(cdiv((n + 63) / 64, 64)), dim3(64), 0, ctx->stream, parent, size, n, lrbits, rootbits);
+    debug_sync(ctx, "cc: roots");
     hipLaunchKernelGGL(cc_rank_blocksum_bits_kernel, dim3(nb), dim3(64), 0, ctx->stream, d_probs, np, size, n, block_sums, counters, rootbits);
     hipLaunchKernelGGL(cc_rank_scan_kernel, dim3(3), dim3(1024), 0, ctx->stream, block_sums, nb, counters);
     int hc[8];
@@ -789,6 +781,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         int *big_root = A.get<int>(n_big), *big_qoff = A.get<int>(n_big), *big_box = A.get<int>(4 * (size_t)n_big);
         if (!big_root || !big_qoff || !big_box) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * 8, ctx->stream));
+        hipLaunchKernelGGL(cc_flatten_all_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, n);
         hipLaunchKernelGGL(cc_big_list_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_probs, np, parent, size, n, newlab,
                            big_root, big_qoff, big_box, counters);
         int hb[8];

@@ -106,7 +106,7 @@ struct SlicBatch {
     int *d_tl_k = nullptr;             // [total_tiles_all][SWEEP_MAXC] centroid indices of a tile's list, ascending
     unsigned *d_tl_fp = nullptr;       // [total_tiles_all][256] per thread: its list slot in each of its wave's four footprints (a byte each)
     int *d_tl_meta = nullptr;          // [total_tiles_all][2] {entries (-1: no list yet, -2: the tile cannot be listed), sweep it was built in}
-    int *d_tl_req = nullptr;           // [total_tiles_all] last sweep in which a centroid that left its margin asked the tile to rebuild
+    int *d_tl_req = nullptr;           // [total_tiles_all] last sweep in which a centroid that left its margin asked the tile to rebuild (-1: none)
     float *d_ref = nullptr;            // [total_cent][2] position a centroid's margin is measured from
     double fscale = 1.0;
     bool exit_on_fixed_point = false;
@@ -168,15 +168,17 @@ struct CcProblem { int H, W; long long pix_off; int min_size; int max_size; };  
 struct CcResolve { const int *parent; const int *newlab; const int *target; int max_hops; int start_label; int mask_label; };
 #if defined(__HIPCC__)
 __device__ __forceinline__ int cc_resolve_label(const CcResolve &R, long long i) {
-    const int r = R.parent[i];
-    if (r < 0) return R.mask_label;
+    // (a pixel's parent is its tile-local root, whose parent is the root of the component: cc.hip, cc_roots_kernel)
+    const int p = R.parent[i];
+    if (p < 0) return R.mask_label;
+    const int r = R.parent[p];
     int nl = R.newlab[r];
     int hops = 0;
     while (nl < 0) {   // a small component follows its adjacency chain
         const int t = R.target[-nl - 2];
         // a chain only leads to components that settled EARLIER: it is acyclic and at most n_small long
         if (t < 0 || ++hops > R.max_hops) { nl = -1; break; }
-        nl = R.newlab[R.parent[t]];
+        nl = R.newlab[R.parent[R.parent[t]]];
     }
     return (nl >= 0) ? nl + R.start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
 }

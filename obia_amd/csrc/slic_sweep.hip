@@ -1375,22 +1375,51 @@ static void launch_assign(obia_ctx *ctx, SlicBatch &b, int ignore_color, int acc
 #undef LAUNCH_K_
 }
 
-// d_mask -> d_mask4 (slic.hpp): thread (q, x) packs the mask bytes of the rows 4q .. 4q+3 at column x into one dword.  Once per
-// batch, 2 bytes of traffic per pixel; every sweep then reads a lane's strip with one load instead of four.
+// d_mask -> d_mask4 (slic.hpp): dword (q, x) = the mask bytes of the rows 4q .. 4q+3 at column x.  Once per batch; every sweep then
+// reads a lane's strip with one load instead of four.  A thread owns four columns of one quad row: four dword loads (one per row:
+// a wave reads 256 contiguous bytes of each), a 4 x 4 byte transpose, one 16-byte store.  A problem whose mask hides nothing is
+// skipped: its sweeps never read the packed mask (slic_assign_body: all_valid).
 __global__ __launch_bounds__(256) void mask_pack4_kernel(const SlicProblem *__restrict__ probs, const uint8_t *__restrict__ mask,
                                                          unsigned *__restrict__ mask4) {
     const SlicProblem P = probs[blockIdx.y];
-    const int nq = (P.H + 3) >> 2;
-    for (int q = blockIdx.x; q < nq; q += gridDim.x)
-        for (int x = threadIdx.x; x < P.W; x += 256) {
-            unsigned w = 0u;
+    if ((long long)P.n_valid == (long long)P.H * (long long)P.W) return;
+    const int nq = (P.H + 3) >> 2, W = P.W;
+    const uint8_t *mb = mask + P.pix_off;
+    unsigned *out = mask4 + P.m4_off;
+    const bool vec = (W % 4 == 0) && (P.pix_off % 4 == 0) && (P.m4_off % 4 == 0) && (reinterpret_cast<uintptr_t>(mask) % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(mask4) % 16 == 0);
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        if (vec) {
+            for (int x4 = threadIdx.x; x4 < (W >> 2); x4 += 256) {
+                unsigned r[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int y = 4 * q + j;
-                if (y < P.H) w |= (unsigned)(mask[P.pix_off + (long long)y * P.W + x] != 0) << (8 * j);
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 4 * q + j;
+                    r[j] = y < P.H ? *reinterpret_cast<const unsigned *>(mb + (long long)y * W + 4 * x4) : 0u;
+                }
+                uint4 o;
+                unsigned *ov = &o.x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {   // column c: byte c of every row, normalised to 0 / 1
+                    unsigned w = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w |= (unsigned)(((r[j] >> (8 * c)) & 0xffu) != 0u) << (8 * j);
+                    ov[c] = w;
+                }
+                *reinterpret_cast<uint4 *>(out + (long long)q * W + 4 * x4) = o;
             }
-            mask4[(long long)P.m4_off + (long long)q * P.W + x] = w;
+        } else {
+            for (int x = threadIdx.x; x < W; x += 256) {
+                unsigned w = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 4 * q + j;
+                    if (y < P.H) w |= (unsigned)(mb[(long long)y * W + x] != 0) << (8 * j);
+                }
+                out[(long long)q * W + x] = w;
+            }
         }
+    }
 }
 
 __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
@@ -1440,14 +1469,15 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         const size_t nt = (size_t)b.total_tiles_all;
         b.d_tl_k = A.get<int>(nt * MAXC);
         b.d_tl_fp = A.get<unsigned>(nt * NT);
-        b.d_tl_meta = A.get<int>(nt * 2);
-        b.d_tl_req = A.get<int>(nt);
+        b.d_tl_meta = A.get<int>(nt * 3);   // {entries, build word} per tile, then the rebuild requests: ONE fill resets all three
+        b.d_tl_req = b.d_tl_meta ? b.d_tl_meta + nt * 2 : nullptr;
         b.d_ref = A.get<float>((size_t)b.total_cent * 2);
         if (!b.d_tl_k || !b.d_tl_fp || !b.d_tl_meta || !b.d_tl_req || !b.d_ref) return OBIA_E_NOMEM;
     }
     int maxh_z = 1;
     for (auto &P : b.probs) if (P.H > maxh_z) maxh_z = P.H;
-    if (b.masked && b.d_mask) {   // the packed mask of the sweeps (problems whose mask hides nothing never read it)
+    if (b.masked && b.d_mask && !b.d_mask4) {   // the packed mask of the sweeps (problems whose mask hides nothing never read it); the
+                                                // tiler's mask kernel writes it on the way (tiling.hip: tile_mask_kernel<true>)
         b.d_mask4 = A.get<unsigned>((size_t)b.total_m4);
         if (!b.d_mask4) return OBIA_E_NOMEM;
         int gq = (maxh_z + 3) / 4;
@@ -1508,9 +1538,8 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
     auto run_all = [&](bool store_all) -> int {
         OBIA_HIP_TRY(hipMemsetAsync(d_px, 0, sizeof(unsigned long long) * 513, ctx->stream));
         OBIA_HIP_TRY(hipMemsetAsync(b.d_head, 0xff, sizeof(int) * (size_t)b.total_cells, ctx->stream));   // buffer 0 only
-        // no tile has a list, nobody asked for a rebuild ({-1, -1} and 0: the first sweep builds every list)
-        OBIA_HIP_TRY(hipMemsetAsync(b.d_tl_meta, 0xff, sizeof(int) * 2 * (size_t)b.total_tiles_all, ctx->stream));
-        OBIA_HIP_TRY(hipMemsetAsync(b.d_tl_req, 0, sizeof(int) * (size_t)b.total_tiles_all, ctx->stream));
+        // no tile has a list, nobody asked for a rebuild (-1 everywhere: the first sweep builds every list)
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_tl_meta, 0xff, sizeof(int) * 3 * (size_t)b.total_tiles_all, ctx->stream));
         debug_sync(ctx, "sweeps: memsets");
         if (groups.size() > 1) {   // fork: the side streams start after everything queued on the context's stream so far
             OBIA_HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));

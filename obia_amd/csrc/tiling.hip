@@ -35,7 +35,7 @@ namespace obia {
 //           it is neither `within` nor `overlaps` (not selected)                                             tiling.py:205-210
 //   cl*_any pixels that meet the square's interior at all: a segment with such a pixel is not `within`       tiling.py:220-231
 // (equal when a is a whole number -- even buffer, pixel size 1 or 0.5 -- which is every case rounds 1-3 tested)
-struct TileWin { int y0, x0, h, w; long long pix_off; int cly, clx; int cly_in, clx_in, cly_any, clx_any; };
+struct TileWin { int y0, x0, h, w; long long pix_off; int cly, clx; int cly_in, clx_in, cly_any, clx_any; int m4_off; };   // m4_off: SlicProblem::m4_off
 
 // wave-aggregated histogram add: lanes of a wave that hold the same key add once
 __device__ __forceinline__ void wave_hist_add(unsigned *hist, int key, bool active) {
@@ -70,23 +70,25 @@ __global__ __launch_bounds__(256) void tile_count_inside_kernel(const TileWin *_
     const TileWin t = wins[blockIdx.y];
     bool seen = false;
     const int wround = ((t.w + 255) / 256) * 256;   // whole waves stay in the loop for the wave-level histogram
-    for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+    for (int y = blockIdx.x; y < t.h; y += gridDim.x) {
+        const bool low = y >= t.h - t.cly_any;   // a row the corner squares reach (workgroup-uniform: the others test no pixel)
         for (int x0 = 0; x0 < wround; x0 += 4 * 256) {   // four loads in flight
             int g[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int x = x0 + 256 * u + threadIdx.x;
                 g[u] = 0;
-                if (x < t.w && !wholly_in_corner(t, y, x)) {
+                if (x < t.w && !(low && wholly_in_corner(t, y, x))) {
                     g[u] = G[(long long)(t.y0 + y) * Wr + t.x0 + x];
                     seen |= g[u] > 0;
-                    if (meets_corner(t, y, x)) g[u] = 0;   // (a pixel the cut passes through: selected, but not counted as inside)
+                    if (low && meets_corner(t, y, x)) g[u] = 0;   // (a pixel the cut passes through: selected, but not counted as inside)
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (x0 + 256 * u < wround) wave_hist_add(inside, g[u], g[u] > 0);   // wave-uniform condition
         }
+    }
     if (__ballot(seen) && (threadIdx.x & 63) == 0) tile_any[blockIdx.y] = 1;   // (every writer stores the same value)
 }
 
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
                                                         int32_t *__restrict__ G, int Wr, int white,
                                                         const unsigned *__restrict__ inside, const unsigned *__restrict__ seg_size,
                                                         uint8_t *__restrict__ alive, uint8_t *__restrict__ dmask,
-                                                        const int *__restrict__ tile_any) {
+                                                        const int *__restrict__ tile_any, unsigned *__restrict__ dmask4) {
     const TileWin t = wins[blockIdx.y];
     // a white tile whose polygon no existing segment intersects keeps the mask it read: neither kept segments (there are none
     // inside the polygon) nor the corner squares are masked out (tiling.py:212, 261-262)
@@ -115,22 +117,44 @@ __global__ __launch_bounds__(256) void tile_mask_kernel(const TileWin *__restric
     if (VEC4) {
         // four consecutive pixels per lane: one dword of mask bytes, one int4 of labels, one dword stored (the host checks that
         // every window's x0, w and pix_off and the row pitch are multiples of four and the base pointers aligned)
-        const int w4 = t.w >> 2;
-        for (int y = blockIdx.x; y < t.h; y += gridDim.x)
+        // A thread owns a 4 x 4 block: the four rows of one quad row (the eight loads in flight together), so that it can also
+        // write the block TRANSPOSED -- the packed mask of the sweeps (SlicBatch::d_mask4: dword (q, x) = the bytes of the rows
+        // 4q .. 4q+3 at column x), which used to be a pass of its own over the batch's mask (round 4).
+        const int w4 = t.w >> 2, nq = (t.h + 3) >> 2;
+        for (int q = blockIdx.x; q < nq; q += gridDim.x)
             for (int x4 = threadIdx.x; x4 < w4; x4 += 256) {
                 const int x = 4 * x4;
-                const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
-                const unsigned mw = inmask ? *reinterpret_cast<const unsigned *>(inmask + gp) : 0x01010101u;
-                int4 g = make_int4(0, 0, 0, 0);
-                if (white) g = *reinterpret_cast<const int4 *>(G + gp);
-                const int gv[4] = {g.x, g.y, g.z, g.w};
-                unsigned out = 0;
+                unsigned mw[4];
+                int4 g[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint8_t m = ((mw >> (8 * u)) & 0xffu) != 0;
-                    out |= (unsigned)decide(y, x + u, gp + u, m, gv[u]) << (8 * u);
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 4 * q + j;
+                    const long long gp = (long long)(t.y0 + (y < t.h ? y : t.h - 1)) * Wr + t.x0 + x;
+                    mw[j] = inmask ? *reinterpret_cast<const unsigned *>(inmask + gp) : 0x01010101u;
+                    g[j] = make_int4(0, 0, 0, 0);
+                    if (white) g[j] = *reinterpret_cast<const int4 *>(G + gp);
                 }
-                *reinterpret_cast<unsigned *>(dmask + t.pix_off + (long long)y * t.w + x) = out;
+                unsigned out[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 4 * q + j;
+                    if (y >= t.h) continue;   // (rows past the window: zero bytes in the packed mask, nothing in the row-major one)
+                    const long long gp = (long long)(t.y0 + y) * Wr + t.x0 + x;
+                    const int gv[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint8_t m = ((mw[j] >> (8 * u)) & 0xffu) != 0;
+                        out[j] |= (unsigned)decide(y, x + u, gp + u, m, gv[u]) << (8 * u);
+                    }
+                    *reinterpret_cast<unsigned *>(dmask + t.pix_off + (long long)y * t.w + x) = out[j];
+                }
+                uint4 o;   // column c of the block: byte c of every row
+                unsigned *ov = &o.x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    ov[c] = ((out[0] >> (8 * c)) & 0xffu) | (((out[1] >> (8 * c)) & 0xffu) << 8) | (((out[2] >> (8 * c)) & 0xffu) << 16) |
+                            (((out[3] >> (8 * c)) & 0xffu) << 24);
+                *reinterpret_cast<uint4 *>(dmask4 + (long long)t.m4_off + (long long)q * t.w + x) = o;
             }
         return;
     }
@@ -361,11 +385,13 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     for (int i = 0; i < 3; ++i) { b.sigma[i] = S.sp.sigma_zyx[i]; b.spacing[i] = S.sp.spacing_zyx[i]; }
     const bool direct = (float)b.spacing[1] != 1.0f || (float)b.spacing[2] != 1.0f;   // anisotropic spacing: the direct sweep path
     if (direct) b.exit_on_fixed_point = false;
-    long long off = 0, foff = 0, boff = 0, maxpix = 1;
+    long long off = 0, foff = 0, boff = 0, maxpix = 1, m4 = 0;
     b.probs.resize(np);
     b.windows.resize(np);
     for (int p = 0; p < np; ++p) {
         wins[p].pix_off = off;
+        wins[p].m4_off = (int)m4;                      // the rule of slic_plan_and_seed (same order of problems): SlicProblem::m4_off
+        m4 += (long long)((wins[p].h + 3) / 4) * wins[p].w;
         SlicProblem P{};
         P.H = wins[p].h; P.W = wins[p].w; P.pix_off = off; P.feat_off = foff; P.XB = feat_xb(wins[p].w); P.fb_off = boff;
         b.probs[p] = P;
@@ -383,6 +409,9 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     TileWin *d_wins = A.get<TileWin>(np);
     b.d_windows = A.get<SrcWindow>(np);
     b.d_mask = A.get<uint8_t>((size_t)off);
+    if (m4 > 0x7fffffffLL) { set_error("tile batch of %lld pixels too large", off); return OBIA_E_INVALID; }
+    unsigned *d_mask4 = A.get<unsigned>((size_t)(m4 > 0 ? m4 : 1));   // the packed mask of the sweeps, written by tile_mask_kernel<true>
+    if (!d_mask4) return OBIA_E_NOMEM;
     const bool pre = white && S.pf.ready;
     if (pre) {
         // this batch is the next np windows of the prefetched set (same order, same sizes: checked)
@@ -416,14 +445,16 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     }
     {
         bool vec4 = (S.W % 4 == 0) && (reinterpret_cast<uintptr_t>(S.inmask) % 4 == 0) && (reinterpret_cast<uintptr_t>(S.G) % 16 == 0) &&
-                    (reinterpret_cast<uintptr_t>(b.d_mask) % 4 == 0);
+                    (reinterpret_cast<uintptr_t>(b.d_mask) % 4 == 0) && (reinterpret_cast<uintptr_t>(d_mask4) % 16 == 0);
         for (auto &t : wins) vec4 = vec4 && (t.x0 % 4 == 0) && (t.w % 4 == 0) && (t.pix_off % 4 == 0);
-        if (vec4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<true>), dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
-                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask, d_tile_any);
-        else
+        if (vec4) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<true>), dim3((grid_rows(wins) + 3) / 4, np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
+                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask, d_tile_any, d_mask4);
+            b.d_mask4 = d_mask4;   // (slic_run_sweeps packs the mask itself when nobody did)
+        } else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_mask_kernel<false>), dim3(grid_rows(wins), np), dim3(256), 0, ctx->stream, d_wins, S.inmask,
-                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask, d_tile_any);
+                               S.G, S.W, white ? 1 : 0, S.inside, S.seg_size, S.alive, b.d_mask, d_tile_any, d_mask4);
+        }
     }
     // per-tile normalisation of every band (create_segments normalises the tile it is given, :32-33)
     std::vector<int> skip;
@@ -563,7 +594,7 @@ static TileWin white_window(const TileState &S, int tj, int ti) {
     const int x0 = std::max(0, ti * T - B), x1 = std::min(S.W, ti * T + T + B);
     const int h = y1 - y0, w = x1 - x0;
     return TileWin{y0 - S.row0, x0, h, w, 0, std::min(S.cly, h), std::min(S.clx, w), std::min(S.cly_in, h), std::min(S.clx_in, w),
-                   std::min(S.cly_any, h), std::min(S.clx_any, w)};
+                   std::min(S.cly_any, h), std::min(S.clx_any, w), 0};
 }
 
 // The feature pass of ALL white tiles runs as ONE batch before the white rows (it depends on the raster only), in the
@@ -682,7 +713,7 @@ static int tiler_run(obia_ctx *ctx, TileState &S, bool white, int tr_lo, int tr_
             const bool is_white = (ti + tj) % 2 != 0;
             if (is_white != white) continue;
             if (!white) {
-                TileWin t{tj * T - S.row0, ti * T, std::min(T, S.Hg - tj * T), std::min(T, S.W - ti * T), 0, 0, 0, 0, 0, 0, 0};
+                TileWin t{tj * T - S.row0, ti * T, std::min(T, S.Hg - tj * T), std::min(T, S.W - ti * T), 0, 0, 0, 0, 0, 0, 0, 0};
                 if (t.h > 0 && t.w > 0) wins.push_back(t);
             } else {
                 const TileWin t = white_window(S, tj, ti);

@@ -191,9 +191,8 @@ def test_masked_slic_on_skimage_seeds_vs_golden(amd, name):
     """maskSLIC pinned on scikit-image itself: the HIP path is fed scikit-image's OWN seeds (the `seeds_yx` /
     `seed_steps_all` the golden generator took from `_get_mask_centroids`, tests/golden/gen_goldens.py) through the
     seeds input of the C ABI (obia_slic_seeded_f32_dev) and compared with scikit-image's OUTPUT, not with the oracle:
-    spatial-only pre-pass + main pass (slic_superpixels.py:310-318) -> labels before connectivity <= 1e-4 of pixels,
-    final labels exact or ARI >= 0.99 with the same segment count.  This is the path every tile of
-    create_tiled_segments takes (tiling.py:121-143)."""
+    spatial-only pre-pass + main pass (slic_superpixels.py:310-318) -> labels identical before and after connectivity.
+    This is the path every tile of create_tiled_segments takes (tiling.py:121-143)."""
     from obia_amd.segmentation import slic
     z, params = load(name)
     raw = dev(z["raw"].astype(np.float32))
@@ -201,15 +200,15 @@ def test_masked_slic_on_skimage_seeds_vs_golden(amd, name):
     seeds = (z["seeds_yx"], z["seed_steps_all"])
     kw = kwargs_of(params)
     pre = slic(raw, mask=mask, seeds=seeds, _normalize_bands=True, _stage="pre", **kw).cpu().numpy()
-    dis = label_disagreement(pre, z["labels_pre"])
-    assert dis <= 1e-4, f"{name}: {dis:.2e} of pixels differ before connectivity (scikit-image seeds)"
     lab = slic(raw, mask=mask, seeds=seeds, _normalize_bands=True, **kw).cpu().numpy()
     gold = z["labels"]
     assert (lab[mask == 0] == 0).all() and (lab[mask != 0] > 0).all()
-    if not np.array_equal(lab, gold):
-        ari = adjusted_rand_index(lab[mask != 0], gold[mask != 0])
-        assert ari >= 0.99, f"{name}: ARI vs scikit-image {ari}"
-        assert len(np.unique(lab)) == len(np.unique(gold))
+    # bit-exact before and after connectivity on all three masked goldens (tools/golden_exactness.py, round 4: 0 / 0 pixels); a case
+    # that stops being exact has to be put on the allow-list with its count, not waved through a tolerance
+    n_pre, n_fin = int((pre != z["labels_pre"]).sum()), int((lab != gold).sum())
+    a_pre, a_fin = NOT_BIT_EXACT.get(name, (0, 0))
+    assert n_pre <= a_pre, f"{name}: {n_pre} pixels differ before connectivity (scikit-image seeds)"
+    assert n_fin <= a_fin, f"{name}: {n_fin} pixels differ after connectivity (scikit-image seeds)"
 
 
 def test_seeded_slic_rejects_bad_seeds(amd):

@@ -1,10 +1,10 @@
 """Fill the @@...@@ placeholders of DESIGN.md / README.md from the artefacts under profiles/ (round-end housekeeping)."""
 import json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-b = json.load(open(os.path.join(root, "profiles", "r03_bench.json")))
-b3 = json.load(open(os.path.join(root, "profiles", "r03_bench_bands3.json")))
+b = json.load(open(os.path.join(root, "profiles", "r04_bench.json")))
+b3 = json.load(open(os.path.join(root, "profiles", "r04_bench_bands3.json")))
 r = b["roofline"]; c = b["compactness_0.25"]; c4 = b["c4_whole_on_one_gpu"]; b9 = b["bands_9"]
-tl = open(os.path.join(root, "profiles", "r03_step_timeline.txt")).readline()
+tl = open(os.path.join(root, "profiles", "r04_step_timeline.txt")).readline()
 vals = {"VALUE": f"{b['value']:.0f}", "MS": f"{b['ms_per_step']:.1f}", "SW": f"{r['avg_launch_ms']:.3f}", "FR": f"{r['frac']:.2f}",
         "RANGE": sys.argv[1] if len(sys.argv) > 1 else "5990–6050", "TLWALL": re.search(r"step wall ([0-9.]+)", tl).group(1),
         "C025": f"{c['value']:.0f}", "C025MS": f"{c['ms_per_step']:.1f}", "C025SW": f"{c['sweep_avg_launch_ms']:.3f}", "C025FR": f"{c['sweep_roofline_frac']:.2f}",

@@ -13,5 +13,7 @@ timeout -k 10 400 python bench.py --config c4 --no-cpu --no-side > gpurun_out/fa
 timeout -k 10 200 python bench.py --bands 3 --no-cpu --no-side --steps 3 --warmup 1 > gpurun_out/fa_bench_bands3.json 2> gpurun_out/fa_b3.err
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fa_step -- python3 tools/step_trace.py > gpurun_out/fa_s.log 2>&1
 python3 tools/trace_gaps.py gpurun_out/fa_step > gpurun_out/fa_step_timeline.txt
-rm -f gpurun_out/fa_trace/*/*kernel_trace.csv gpurun_out/fa_step/*/*kernel_trace.csv   # (tens of MB; the statistics are what is kept)
+OBIA_TRACE_COMPACTNESS=0.25 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fa_step025 -- python3 tools/step_trace.py > gpurun_out/fa_s025.log 2>&1
+python3 tools/trace_gaps.py gpurun_out/fa_step025 > gpurun_out/fa_step_timeline_c025.txt
+rm -f gpurun_out/fa_trace/*/*kernel_trace.csv gpurun_out/fa_step/*/*kernel_trace.csv gpurun_out/fa_step025/*/*kernel_trace.csv   # (tens of MB; the statistics are what is kept)
 echo artefacts done

@@ -1,7 +1,7 @@
-"""profiles/r03_traffic.json from two rocprofv3 --pmc passes of tools/step_trace.py (the bench workload):
+"""profiles/r04_traffic.json from two rocprofv3 --pmc passes of tools/step_trace.py (the bench workload):
      rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/step_trace.py
      rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/step_trace.py
-     python3 tools/traffic_json.py gpurun_out/pmc_fetch gpurun_out/pmc_write <commit> > profiles/r03_traffic.json
+     python3 tools/traffic_json.py gpurun_out/pmc_fetch gpurun_out/pmc_write <commit> > profiles/r04_traffic.json
 Units: the counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md,
 HBM section; calibrated on features_kernel, which reads and writes exactly 32 B/pixel) -- doubled here."""
 import csv, glob, json, os, sys, collections
