@@ -271,6 +271,21 @@ int obia_tiler_set_segments(obia_tiler *t, int first_id, int count, const uint32
 int obia_tiler_get_alive(obia_tiler *t, uint8_t *alive_out_dev, int count);
 int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count);
 int obia_tiler_finalize(obia_tiler *t, int64_t *n_segments_out);
+/* Import of a seam (round 4): the boundary label rows a neighbouring rank sent, as wire codes, become local ids in ONE call --
+ * the step between `ncclRecv` and the next pass (semantic anchor obia/utils/tiling.py:289-290: one id space).
+ *   codes_dev [n]        int32: (owner_rank + 1) << 24 | the owner's local id; 0 = no segment
+ *   fmap_dev [fmap_cap]  int32, persistent per (session, owner): the owner's local id -> my local id, 0 = not imported yet
+ *   code_of_dev [cap]    int32, persistent per session: my local id -> wire code of an imported segment (0: one of my own);
+ *                        the caller keeps cap above obia_tiler_next_id() + n
+ *   ids_out_dev [n]      int32: my local ids (codes of `my_rank` map to their id field, codes of other owners to 0)
+ * Codes of `owner_rank` that are not in fmap yet get consecutive new local ids in ascending order of the owner's ids, starting
+ * at *first_new_out = obia_tiler_next_id(); the range is registered like obia_tiler_set_segments(first, n_new, 0xffffffff...)
+ * (sizes follow from the caller's view of its halo).  *max_owner_id_out = the largest owner id on the seam: when it is
+ * >= fmap_cap the ids beyond the map were left out (ids_out 0) and the caller calls again with a larger map (entries kept; what
+ * the first call imported -- *n_new_out ids from *first_new_out -- stays imported).                                          */
+int obia_tiler_import_seam(obia_tiler *t, const int32_t *codes_dev, int n, int my_rank, int owner_rank,
+                           int32_t *fmap_dev, int fmap_cap, int32_t *code_of_dev, int32_t *ids_out_dev,
+                           int *first_new_out, int *n_new_out, int *max_owner_id_out);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------
  * Time of the most recent call's kernels by class, measured with HIP events on the context's

@@ -71,6 +71,8 @@ struct obia_ctx {
     obia::Arena arena;
     void *pinned = nullptr;          // small pinned host staging buffer for scalar read-backs
     size_t pinned_bytes = 0;
+    unsigned long long *defer_buf = nullptr;   // pinned landing area of a read-back that is looked at after a LATER synchronisation
+    bool defer_pending = false;                // (slic_run_sweeps with defer: the orphan flag and pixel counters of the sweeps)
     char *up_buf = nullptr;          // pinned ring for small host -> device tables (upload_async): no stream sync per upload
     size_t up_bytes = 0, up_used = 0;
     int profiling = 0;               // 0 off, 1 every span, 2 only the colour sweeps (obia_set_profiling)

@@ -184,6 +184,7 @@ void resolve_timing(obia_ctx *ctx) {
 int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes > ctx->pinned_bytes) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->defer_buf) (void)hipHostFree(ctx->defer_buf);
         ctx->pinned = nullptr;
         size_t want = bytes < 4096 ? 4096 : bytes;
         OBIA_HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));

@@ -156,7 +156,14 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
 int slic_count_valid(obia_ctx *ctx, SlicBatch &b, std::vector<int> &nvalid);
 
 // Runs the sweeps; labels (pre-connectivity) land in b.d_labels.
-int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b);
+// mode 0: complete when it returns (one read-back: the orphan flag -- a valid pixel no window reached makes the batch run again with
+//         every sweep storing its labels -- and the profiling counters).
+// mode 1: the read-back is only QUEUED (round 4: one host round trip less per batch).  The caller synchronises the stream for its own
+//         reasons afterwards (the connectivity stage reads its counters back) and then calls slic_sweeps_settle(); when that reports
+//         `repeat`, the labels are not final: the caller runs mode 2 and whatever it had computed from the labels again.
+// mode 2: the repeat itself (every sweep stores its labels), complete when it returns.
+int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b, int mode = 0);
+int slic_sweeps_settle(obia_ctx *ctx, SlicBatch &b, bool *repeat);
 
 // Connectivity enforcement on a batch of dense label maps laid out back to back (pix_off); labels come
 // out consecutive over the whole batch, in problem order then raster order of each component's first pixel.

@@ -267,8 +267,14 @@ __global__ __launch_bounds__(64) void slic_prep_lane_kernel(const SlicProblem *_
     float4 oc[CP / 4];
     ulonglong2 aq[NQ];
     if (!first) {
+        // (the old colours are only compared with the new ones, for the stamps of exit_on_fixed_point: not read otherwise)
+        if (bin_stamp) {
 #pragma unroll
-        for (int i = 0; i < CP / 4; ++i) oc[i] = hrec[2 + i];
+            for (int i = 0; i < CP / 4; ++i) oc[i] = hrec[2 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < CP / 4; ++i) oc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) aq[i] = a2[i];
     }
@@ -1426,7 +1432,7 @@ __global__ void fill_i32_kernel(int32_t *p, long long n, int32_t v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
 
-int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
+int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b, int mode) {
     auto fill_labels = [&]() {   // nearest[:] = start_label - 1, once (before the loop of _slic_cython)
         long long n = b.total_pix;
         int blocks = cdiv(n, 256 * 8);
@@ -1656,8 +1662,23 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         fill_labels();
         debug_sync(ctx, "sweeps: label fill");
     }
-    OBIA_TRY(run_all(store_all));
     unsigned long long h[513];
+    if (mode == 2) {   // the repeat of a batch whose deferred flag said "orphan": every sweep stores its labels
+        fill_labels();
+        OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * (size_t)b.total_cent * RQ, ctx->stream));
+        OBIA_TRY(run_all(true));
+        OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
+        if (ctx->profiling)
+            for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
+        return OBIA_OK;
+    }
+    OBIA_TRY(run_all(store_all));
+    if (mode == 1 && !store_all) {   // the flag and the counters travel to pinned memory behind the sweeps; looked at in slic_sweeps_settle
+        if (!ctx->defer_buf) OBIA_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->defer_buf), sizeof(h), hipHostMallocDefault));
+        OBIA_HIP_TRY(hipMemcpyAsync(ctx->defer_buf, d_px, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->defer_pending = true;
+        return OBIA_OK;
+    }
     OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
     if (!store_all && (h[512] & 0xffffffffull) != 0ull) {
         // a pixel needed the label of an earlier sweep: repeat the batch from the seeds with every sweep storing its labels
@@ -1666,6 +1687,19 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b) {
         OBIA_TRY(run_all(true));
         OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
     }
+    if (ctx->profiling)
+        for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
+    return OBIA_OK;
+}
+
+// (see slic.hpp) the stream has been synchronised since slic_run_sweeps(..., 1) returned
+int slic_sweeps_settle(obia_ctx *ctx, SlicBatch &b, bool *repeat) {
+    (void)b;
+    *repeat = false;
+    if (!ctx->defer_pending) return OBIA_OK;
+    ctx->defer_pending = false;
+    const unsigned long long *h = ctx->defer_buf;
+    if ((h[512] & 0xffffffffull) != 0ull) { *repeat = true; return OBIA_OK; }   // (the repeat counts its own pixels)
     if (ctx->profiling)
         for (int i = 0; i < 256; ++i) { ctx->timing.assign_px += (double)h[i]; ctx->timing.prepass_px += (double)h[256 + i]; }
     return OBIA_OK;

@@ -485,7 +485,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, &nvalid));
     debug_sync(ctx, "tiler: plan_and_seed");
     if (!white && S.pf.d_feat && !S.pf.launched && white_features_beside()) OBIA_TRY(prefetch_white_launch(ctx, S, true));
-    OBIA_TRY(slic_run_sweeps(ctx, b));
+    OBIA_TRY(slic_run_sweeps(ctx, b, 1));   // (the orphan flag is looked at after the connectivity stage's own synchronisation)
     debug_sync(ctx, "tiler: sweeps");
     int n_new = 0;
     CcResolve resolve{};
@@ -499,6 +499,12 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
             cps[p] = CcProblem{P.H, P.W, P.pix_off, (int)(S.sp.min_size_factor * segment_size), mx > 0 ? mx : 1};
         }
         OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new, &resolve));
+        bool repeat = false;
+        OBIA_TRY(slic_sweeps_settle(ctx, b, &repeat));
+        if (repeat) {   // rare: a valid pixel no window reached kept a label that was not stored -- sweeps with stored labels, stage again
+            OBIA_TRY(slic_run_sweeps(ctx, b, 2));
+            OBIA_TRY(enforce_connectivity_batch(ctx, cps, b.d_labels, b.total_pix, 1, d_final, &n_new, &resolve));
+        }
         debug_sync(ctx, "tiler: connectivity");
     } else {
         set_error("the tiled driver needs enforce_connectivity=True (segments must be connected pixel sets)");
@@ -517,6 +523,87 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     // (no synchronisation here: every host table of the batch went through upload_async, and the arena is reused in stream order)
     A.rewind(mk);
     return OBIA_OK;
+}
+
+// ---- seam import (sharded driver): wire codes -> local ids -------------------------------------------------------------------
+// 1. every code is translated where it can be (my own ids, ids of `owner` that are in the map); a code of `owner` whose id is not in
+//    the map yet claims its map entry (0 -> -1: one claimant per id) and joins the list of new ids; the largest owner id on the
+//    seam goes to ctr[1].  An import that meets no new id -- the write-back imports, half of all -- is complete after this kernel.
+__global__ __launch_bounds__(256) void seam_mark_kernel(const int32_t *__restrict__ codes, int n, int me, int owner, int32_t *__restrict__ fmap,
+                                                        int cap, int *__restrict__ new_list, int *__restrict__ ctr, int32_t *__restrict__ ids) {
+    int tmax = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = codes[i];
+        int id = 0;
+        if (c > 0) {
+            const int o = (c >> 24) - 1, t = c & 0xffffff;
+            if (o == me) id = t;
+            else if (o == owner) {
+                tmax = max(tmax, t);
+                if (t > 0 && t < cap) {
+                    const int f = fmap[t];
+                    if (f > 0) id = f;
+                    else if (f == 0 && atomicCAS(&fmap[t], 0, -1) == 0) new_list[atomicAdd(&ctr[0], 1)] = t;
+                }
+            }
+        }
+        ids[i] = id;      // (0 for a new id: seam_translate_kernel fills it in)
+    }
+    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+    if ((threadIdx.x & 63) == 0 && tmax > 0) atomicMax(&ctr[1], tmax);
+}
+// 2. a new id's local id = first + its rank among the new ids (ascending ids of the owner); its wire code is noted.  One workgroup sorts
+//    the list in LDS (bitonic, up to SEAM_SORT entries: a seam of BASELINE configs[3] brings ~7 000 new ids); longer lists are ranked
+//    by counting (seam_assign_count_kernel).
+constexpr int SEAM_SORT = 16384;
+__global__ __launch_bounds__(1024) void seam_assign_sort_kernel(int *__restrict__ new_list, int m, int first, int owner,
+                                                                int32_t *__restrict__ fmap, int32_t *__restrict__ code_of) {
+    __shared__ int s[SEAM_SORT];
+    int np2 = 1;
+    while (np2 < m) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += 1024) s[i] = i < m ? new_list[i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = s[i], b = s[ixj];
+                    if (((i & k) == 0) ? (a > b) : (a < b)) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < m; i += 1024) {
+        const int t = s[i];
+        fmap[t] = first + i;
+        code_of[first + i] = t | ((owner + 1) << 24);
+    }
+}
+__global__ __launch_bounds__(256) void seam_assign_count_kernel(const int *__restrict__ new_list, int m, int first, int owner,
+                                                                int32_t *__restrict__ fmap, int32_t *__restrict__ code_of) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int t = new_list[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += new_list[j] < t;
+        fmap[t] = first + rank;
+        code_of[first + rank] = t | ((owner + 1) << 24);
+    }
+}
+// 3. the codes of the new ids, translated (only launched when there are new ids)
+__global__ __launch_bounds__(256) void seam_translate_kernel(const int32_t *__restrict__ codes, int n, int owner,
+                                                             const int32_t *__restrict__ fmap, int cap, int32_t *__restrict__ ids) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (ids[i] != 0) continue;
+        const int c = codes[i];
+        if (c <= 0 || (c >> 24) - 1 != owner) continue;
+        const int t = c & 0xffffff;
+        if (t > 0 && t < cap) ids[i] = fmap[t];
+    }
+}
+__global__ void seam_register_kernel(unsigned *__restrict__ seg_size, uint8_t *__restrict__ alive, int first, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { seg_size[first + i] = 0xffffffffu; alive[first + i] = 1; }
 }
 
 static int tiler_check(const float *img, int H, int W, int C, int Hg, int row0, const obia_tiling_params *tp,
@@ -772,6 +859,8 @@ static int tiled_slic_dev(obia_ctx *ctx, const float *img, const uint8_t *mask, 
 struct obia_tiler {
     obia_ctx *ctx;
     obia::TileState S;
+    int *seam_buf = nullptr;      // scratch of obia_tiler_import_seam: two counters + the list of new ids
+    size_t seam_cap = 0;
 };
 
 // Error path: nothing this library queued may still be running when the caller gets the error back (the white tiles'
@@ -805,6 +894,7 @@ obia_tiler *obia_tiler_create(obia_ctx *ctx, const float *img_local, const uint8
 void obia_tiler_destroy(obia_tiler *t) {
     if (!t) return;
     (void)fail_quiesced(t->ctx, 0);   // (a session dropped half-way may have left the white feature pass on its side stream)
+    if (t->seam_buf) (void)hipFree(t->seam_buf);
     resolve_timing(t->ctx);
     delete t;
 }
@@ -842,6 +932,48 @@ int obia_tiler_set_alive(obia_tiler *t, const uint8_t *alive_in_dev, int count) 
     if (!t || !alive_in_dev || count < 0 || count > t->S.id_cap) { set_error("bad arguments"); return OBIA_E_INVALID; }
     OBIA_HIP_TRY(hipMemcpyAsync(t->S.alive, alive_in_dev, (size_t)count, hipMemcpyDeviceToDevice, t->ctx->stream));
     OBIA_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return OBIA_OK;
+}
+
+int obia_tiler_import_seam(obia_tiler *t, const int32_t *codes_dev, int n, int my_rank, int owner_rank,
+                           int32_t *fmap_dev, int fmap_cap, int32_t *code_of_dev, int32_t *ids_out_dev,
+                           int *first_new_out, int *n_new_out, int *max_owner_id_out) {
+    if (!t || !codes_dev || !fmap_dev || !code_of_dev || !ids_out_dev || n < 0 || fmap_cap < 1 || my_rank < 0 || owner_rank < 0 ||
+        my_rank > 126 || owner_rank > 126 || !first_new_out || !n_new_out || !max_owner_id_out) { set_error("bad arguments"); return OBIA_E_INVALID; }
+    obia_ctx *ctx = t->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return OBIA_E_HIP; }
+    *first_new_out = t->S.next_id; *n_new_out = 0; *max_owner_id_out = 0;
+    if (n == 0) return OBIA_OK;
+    // scratch outside the arena (the session's arena holds the tiler's persistent state): one small allocation kept by the session
+    if (t->seam_cap < (size_t)n + 2) {
+        if (t->seam_buf) (void)hipFree(t->seam_buf);
+        t->seam_buf = nullptr; t->seam_cap = 0;
+        if (hipMalloc(&t->seam_buf, sizeof(int) * ((size_t)n + 2)) != hipSuccess) { set_error("seam scratch allocation failed"); return OBIA_E_NOMEM; }
+        t->seam_cap = (size_t)n + 2;
+    }
+    int *ctr = t->seam_buf, *new_list = t->seam_buf + 2;
+    OBIA_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(int) * 2, ctx->stream));
+    const int blocks = std::min(cdiv(n, 256), 2048);
+    hipLaunchKernelGGL(seam_mark_kernel, dim3(blocks), dim3(256), 0, ctx->stream, codes_dev, n, my_rank, owner_rank, fmap_dev, fmap_cap, new_list, ctr,
+                       ids_out_dev);
+    int h[2] = {0, 0};
+    OBIA_TRY(read_back(ctx, h, ctr, sizeof(h)));   // the one read-back of an import: how many ids are new, the largest id on the seam
+    *max_owner_id_out = h[1];
+    const int n_new = h[0];
+    if (t->S.next_id + n_new > t->S.id_cap) { set_error("segment id capacity exceeded (%d + %d > %d)", t->S.next_id, n_new, t->S.id_cap); return OBIA_E_NOMEM; }
+    if (n_new > 0) {
+        if (n_new <= SEAM_SORT)
+            hipLaunchKernelGGL(seam_assign_sort_kernel, dim3(1), dim3(1024), 0, ctx->stream, new_list, n_new, t->S.next_id, owner_rank, fmap_dev, code_of_dev);
+        else
+            hipLaunchKernelGGL(seam_assign_count_kernel, dim3(256), dim3(256), 0, ctx->stream, new_list, n_new, t->S.next_id, owner_rank, fmap_dev, code_of_dev);
+        hipLaunchKernelGGL(seam_translate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, codes_dev, n, owner_rank, fmap_dev, fmap_cap, ids_out_dev);
+        // registered like obia_tiler_set_segments(first, n_new, 0xffffffff ...): sizes follow from the caller's halo
+        hipLaunchKernelGGL(seam_register_kernel, dim3(cdiv(n_new, 256)), dim3(256), 0, ctx->stream, t->S.seg_size, t->S.alive, t->S.next_id, n_new);
+        t->S.next_id += n_new;
+    }
+    *n_new_out = n_new;   // (when h[1] >= fmap_cap the ids beyond the map were not translated: the caller calls again with a larger map;
+                          // what this call imported stays imported)
+    OBIA_HIP_TRY(hipGetLastError());
     return OBIA_OK;
 }
 

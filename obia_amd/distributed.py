@@ -21,6 +21,7 @@ compute engine is injectable so that the protocol is also exercised on CPU (gloo
 tests/test_distributed_cpu.py with the oracle's tiler as engine.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -80,6 +81,17 @@ class HipTilerEngine:
         s = torch.where(s >= 2 ** 31, s - 2 ** 32, s).to(torch.int32).contiguous()   # uint32 bit pattern
         torch.cuda.current_stream(self.G.device).synchronize()
         _lib.check(self.lib.obia_tiler_set_segments(self.h, int(first_id), int(s.numel()), s.data_ptr()))
+
+    def import_seam(self, codes, my_rank, owner, fmap, code_of):
+        """obia_tiler_import_seam: int32 wire codes (any shape) -> (int32 local ids of the same shape, first new id, number of new
+        ids, largest owner id on the seam); fmap / code_of are updated in place"""
+        c = codes.to(device=self.G.device, dtype=torch.int32).contiguous()
+        out = torch.empty_like(c)
+        first, n_new, t_max = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        torch.cuda.current_stream(self.G.device).synchronize()
+        _lib.check(self.lib.obia_tiler_import_seam(self.h, c.data_ptr(), int(c.numel()), int(my_rank), int(owner), fmap.data_ptr(), int(fmap.numel()),
+                                                   code_of.data_ptr(), out.data_ptr(), ctypes.byref(first), ctypes.byref(n_new), ctypes.byref(t_max)))
+        return out, first.value, n_new.value, t_max.value
 
     def get_alive(self, n):
         out = torch.zeros((int(n),), dtype=torch.uint8, device=self.G.device)
@@ -363,6 +375,8 @@ class ShardedTiler:
         64-MB table per neighbour and swept it eight times per import): it starts at twice this rank's own id count -- slabs
         of one raster hold similar numbers of segments -- and doubles past the largest id on a seam; that largest id rides
         in the import's one read-back, and an import whose seam outgrew the map is simply evaluated again on the grown map."""
+        if hasattr(self.engine, "import_seam") and len(owners) == 1 and not os.environ.get("OBIA_SEAM_IMPORT_TORCH"):
+            return self._ids_of_kernel(codes, owners[0])
         codes = codes.to(torch.int64)
         their = codes & ID_MASK
         owner = (codes >> CODE_SHIFT) - 1
@@ -408,6 +422,36 @@ class ShardedTiler:
             ids = torch.where(sel, fm[tc].to(torch.int64), ids)
         self.stats["imports"] += 1
         return ids
+
+    def _ids_of_kernel(self, codes, nb):
+        """_ids_of through the library (obia_tiler_import_seam): three small kernels and one read-back behind the C ABI where the
+        torch form below takes ~25 launches (Missing 3).  Same result, same bookkeeping."""
+        gdev = self.G.device
+        fm = self.fmap.get(nb)
+        if fm is None:
+            cap0 = 1 << max(12, (2 * int(self.engine.next_id())).bit_length())
+            fm = self.fmap[nb] = torch.zeros((min(cap0, 1 << CODE_SHIFT),), dtype=torch.int32, device=gdev)
+        while True:
+            need = int(self.engine.next_id()) + int(codes.numel()) + 1          # every code could be a new segment
+            if need >= (1 << CODE_SHIFT):
+                need = 1 << CODE_SHIFT
+            if self.code_of.numel() < need:
+                grown = torch.zeros((max(need, 2 * self.code_of.numel()),), dtype=torch.int32, device=gdev)
+                grown[:self.code_of.numel()] = self.code_of
+                self.code_of = grown
+            ids, first, n_new, t_max = self.engine.import_seam(codes, self.rank, nb, fm, self.code_of)
+            if n_new:
+                self._check_ids()
+                self.f_batches.append((nb, first, n_new))
+                self.stats["foreign_ids"] += n_new
+            if t_max < fm.numel():
+                break
+            grown = torch.zeros((min(1 << CODE_SHIFT, 1 << (2 * int(t_max) + 2).bit_length()),), dtype=torch.int32, device=gdev)
+            grown[:fm.numel()] = fm
+            fm = self.fmap[nb] = grown
+            self.stats["map_growths"] = self.stats.get("map_growths", 0) + 1
+        self.stats["imports"] += 1
+        return ids.reshape(codes.shape).to(torch.int64)
 
     def _foreign_ids(self, owner=None):
         """all local ids of imported segments (of one owner), ascending"""

@@ -123,3 +123,54 @@ def test_rccl_backend_wiring_with_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("nccl one-rank ok")]
     assert line and line[0].endswith("True"), out.stdout[-500:]
+
+
+def test_seam_import_kernel_equals_the_torch_form():
+    """obia_tiler_import_seam (three kernels and one read-back behind the C ABI, VERDICT r3 Missing 3) against the torch form of
+    ShardedTiler._ids_of that it replaces: the same local ids, id ranges, maps and codes over a sequence of imports -- repeats,
+    codes of my own rank, codes of a third rank, an owner id beyond the map (the map is grown and the import repeated)."""
+    from obia_amd.distributed import ShardedTiler, ThreadComm, CODE_SHIFT
+    rs = np.random.RandomState(5)
+    img = torch.as_tensor(synth(160, 200, 4)).cuda()
+
+    def make(torch_form, monkey_env):
+        comm = ThreadComm.make(1)[0]
+        if torch_form:
+            monkey_env["OBIA_SEAM_IMPORT_TORCH"] = "1"
+        else:
+            monkey_env.pop("OBIA_SEAM_IMPORT_TORCH", None)
+        from obia_amd import _lib
+        return ShardedTiler(img, None, 160, 2, 80, 8, 4, (1.0, 1.0), comm=comm, ctx=_lib.Context(0))   # (a session owns its context)
+    a, b = make(False, os.environ), None
+    try:
+        seams = []
+        for step in range(5):
+            hi = [300, 300, 9000, 9000, 70000][step]            # (70000 lies beyond the first map: one growth)
+            t = rs.randint(1, hi, size=(9, 200))
+            owner = rs.choice([2, 2, 2, 1, 3], size=(9, 200))   # rank 2 is the neighbour, 1 is me, 3 somebody else
+            codes = np.where(rs.rand(9, 200) < 0.2, 0, t + ((owner + 1) << CODE_SHIFT)).astype(np.int32)
+            seams.append(torch.as_tensor(codes).cuda())
+        a.rank = 1
+        os.environ.pop("OBIA_SEAM_IMPORT_TORCH", None)
+        got = [a._ids_of(c, (2,)).clone() for c in seams]
+        os.environ["OBIA_SEAM_IMPORT_TORCH"] = "1"
+        b = make(True, os.environ)
+        b.rank = 1
+        want = [b._ids_of(c, (2,)).clone() for c in seams]
+        for g, w in zip(got, want):
+            assert torch.equal(g.to(torch.int64), w.to(torch.int64))
+        # (the same imported ids; an import that had to grow the map registers its ids in two ranges where the torch form has one)
+        assert torch.equal(a._foreign_ids(), b._foreign_ids()) and a.stats["foreign_ids"] == b.stats["foreign_ids"]
+        assert a.stats.get("map_growths", 0) >= 1
+        n = int(a.engine.next_id())
+        assert n == int(b.engine.next_id())
+        assert torch.equal(a.code_of[:n], b.code_of[:n])
+        assert torch.equal(a.engine.get_alive(n), b.engine.get_alive(n))
+        fa, fb = a.fmap[2], b.fmap[2]
+        m = min(fa.numel(), fb.numel())
+        assert torch.equal(fa[:m], fb[:m]) and not fa[m:].any() and not fb[m:].any()
+    finally:
+        os.environ.pop("OBIA_SEAM_IMPORT_TORCH", None)
+        a.close()
+        if b is not None:
+            b.close()

@@ -79,6 +79,31 @@ elif mode == "ids":
         print(f"{'dense 2^24 map (round 2)' if dense else 'sized map (round 3)   '}: first import {1e3*(t1-t0):.3f} ms, repeat import {1e3*(t2-t1):.3f} ms, "
               f"map entries {t.fmap[2].numel()}, foreign ids {t.stats['foreign_ids']}", flush=True)
 
+elif mode == "idsk":
+    # the same seam through obia_tiler_import_seam (round 4: three kernels and one read-back behind the C ABI) on a real session
+    from obia_amd import _lib
+    from obia_amd import distributed as D
+    W, hb = 32768, 65
+    seg_of_col = (torch.arange(W, device=DEV) // 18)
+    rows = torch.arange(hb, device=DEV)[:, None] // 18
+    their = 440_000 + rows * (W // 18 + 1) + seg_of_col[None, :]
+    codes = (their + ((2 + 1) << D.CODE_SHIFT)).to(torch.int32)
+    img = torch.rand((256, 256, 4), device=DEV)
+    for rep in range(4):
+        t = D.ShardedTiler(img, None, 256, 2, 128, 16, 4, (1.0, 1.0), comm=D.ThreadComm.make(1)[0], ctx=_lib.Context(0))
+        t.rank = 3
+        t.engine.close()
+        t.engine = D.HipTilerEngine(img, torch.ones((256, 256), dtype=torch.uint8, device=DEV), 256, 0, 128, 16, 4, (1.0, 1.0), {}, 20000, ctx=_lib.Context(0))
+        t.fmap[2] = torch.zeros((1 << 20,), dtype=torch.int32, device=DEV)
+        torch.cuda.synchronize(); t0 = time.time()
+        ids = t._ids_of(codes, (2,))
+        torch.cuda.synchronize(); t1 = time.time()
+        ids2 = t._ids_of(codes, (2,))
+        torch.cuda.synchronize(); t2 = time.time()
+        assert torch.equal(ids, ids2) and t.stats["foreign_ids"] == int(their.unique().numel())
+        t.close()
+    print(f"obia_tiler_import_seam (round 4): first import {1e3*(t1-t0):.3f} ms, repeat import {1e3*(t2-t1):.3f} ms, foreign ids {t.stats['foreign_ids']}", flush=True)
+
 elif mode == "c4":
     import threading
     from bench import synth_raster
