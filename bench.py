@@ -541,7 +541,13 @@ def main():
                        "pixel_size_m": 0.5, "compactness": args.compactness, "max_num_iter": 10, "mask": "all-ones",
                        "segments": int(n_seg), "parallelism": f"slab{world}" if world > 1 else "1gpu",
                        "backend": (backend if world > 1 else None), "devices": (min(world, n_dev) if world > 1 else 1)},
-            "roofline": {"bound": "hbm", "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false,{C}>",
+            # bound: the roofline the fraction is taken against (BASELINE's metric: achieved HBM GB/s fraction).  limited_by: what the
+            # round-4 counters say stands in the way -- SQ_ACTIVE_INST_VALU 12.1 k cycles per wave x 6 waves per SIMD against
+            # SQ_WAVE_CYCLES 73.6 k: the vector ALUs are 98 % busy in steady state (profiles/r04_notes.md, r04_pmc_sweep_kernels.txt);
+            # with no feature / mask traffic at all the launch is 8 % shorter (OBIA_ABL_NOLOAD).  Dated figures, not live ones.
+            "roofline": {"bound": "hbm", "limited_by": "valu", "valu_busy_steady_state": 0.98,
+                         "limited_by_source": "profiles/r04_notes.md section 2 (PMC passes at 8192^2, round 4)",
+                         "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false,{C}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,

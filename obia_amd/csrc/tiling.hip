@@ -970,6 +970,9 @@ int obia_tiler_import_seam(obia_tiler *t, const int32_t *codes_dev, int n, int m
         // registered like obia_tiler_set_segments(first, n_new, 0xffffffff ...): sizes follow from the caller's halo
         hipLaunchKernelGGL(seam_register_kernel, dim3(cdiv(n_new, 256)), dim3(256), 0, ctx->stream, t->S.seg_size, t->S.alive, t->S.next_id, n_new);
         t->S.next_id += n_new;
+        // (the session's entry points return with their work done -- the caller reads ids_out on a stream of its own; an import
+        // that brought nothing new was complete at the read-back above)
+        OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     *n_new_out = n_new;   // (when h[1] >= fmap_cap the ids beyond the map were not translated: the caller calls again with a larger map;
                           // what this call imported stays imported)

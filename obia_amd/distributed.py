@@ -451,7 +451,7 @@ class ShardedTiler:
             fm = self.fmap[nb] = grown
             self.stats["map_growths"] = self.stats.get("map_growths", 0) + 1
         self.stats["imports"] += 1
-        return ids.reshape(codes.shape).to(torch.int64)
+        return ids.reshape(codes.shape)      # (int32, the dtype of the label raster the callers write it into)
 
     def _foreign_ids(self, owner=None):
         """all local ids of imported segments (of one owner), ascending"""

@@ -93,16 +93,20 @@ elif mode == "idsk":
         t = D.ShardedTiler(img, None, 256, 2, 128, 16, 4, (1.0, 1.0), comm=D.ThreadComm.make(1)[0], ctx=_lib.Context(0))
         t.rank = 3
         t.engine.close()
-        t.engine = D.HipTilerEngine(img, torch.ones((256, 256), dtype=torch.uint8, device=DEV), 256, 0, 128, 16, 4, (1.0, 1.0), {}, 20000, ctx=_lib.Context(0))
+        t.engine = D.HipTilerEngine(img, torch.ones((256, 256), dtype=torch.uint8, device=DEV), 256, 0, 128, 16, 4, (1.0, 1.0), {}, 40000, ctx=_lib.Context(0))
         t.fmap[2] = torch.zeros((1 << 20,), dtype=torch.int32, device=DEV)
+        t.code_of = torch.zeros((1 << 22,), dtype=torch.int32, device=DEV)
+        warm = (their - 20_000 + ((2 + 1) << D.CODE_SHIFT)).to(torch.int32)      # another 7 284 ids: the session's first import also
+        t._ids_of(warm, (2,))                                                     # allocates its scratch (once per session)
         torch.cuda.synchronize(); t0 = time.time()
-        ids = t._ids_of(codes, (2,))
+        ids = t._ids_of(codes, (2,))                 # every id is new
         torch.cuda.synchronize(); t1 = time.time()
-        ids2 = t._ids_of(codes, (2,))
+        ids2 = t._ids_of(codes, (2,))                # write-back import: every id is known
         torch.cuda.synchronize(); t2 = time.time()
-        assert torch.equal(ids, ids2) and t.stats["foreign_ids"] == int(their.unique().numel())
+        assert torch.equal(ids, ids2) and t.stats["foreign_ids"] == 2 * int(their.unique().numel())
         t.close()
-    print(f"obia_tiler_import_seam (round 4): first import {1e3*(t1-t0):.3f} ms, repeat import {1e3*(t2-t1):.3f} ms, foreign ids {t.stats['foreign_ids']}", flush=True)
+    print(f"obia_tiler_import_seam (round 4): import of 7 284 new ids {1e3*(t1-t0):.3f} ms, repeat import {1e3*(t2-t1):.3f} ms "
+          f"(65 x 32768 codes; the torch form of round 3 below)", flush=True)
 
 elif mode == "c4":
     import threading
