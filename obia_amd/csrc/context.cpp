@@ -184,7 +184,6 @@ void resolve_timing(obia_ctx *ctx) {
 int read_back(obia_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes > ctx->pinned_bytes) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->defer_buf) (void)hipHostFree(ctx->defer_buf);
         ctx->pinned = nullptr;
         size_t want = bytes < 4096 ? 4096 : bytes;
         OBIA_HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
@@ -281,6 +280,7 @@ void obia_destroy(obia_ctx *ctx) {
     ctx->arena.release();
     if (ctx->up_buf) (void)hipHostFree(ctx->up_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->defer_buf) (void)hipHostFree(ctx->defer_buf);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < obia_ctx::MAX_SIDE; ++i) {
         if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
