@@ -297,6 +297,8 @@ int obia_tiler_import_seam(obia_tiler *t, const int32_t *codes_dev, int n, int m
  * 10 / 11 = time during which at least one colour / pre-pass sweep was running (equals 0 / 6 unless the batch's problems run
  * as groups on side streams, OBIA_SWEEP_GROUPS).  The events of a sweep are bound to its dispatch (hipExtLaunchKernelGGL): 0 and
  * 6 are sums of the kernels' own start-to-end times, as a rocprofv3 kernel trace reports them.
+ * 12 = batches of the call whose sweeps ran a second time with every sweep storing its labels (a valid pixel that no window
+ * reached keeps the label of the sweep before: DESIGN.md 3.2 item 5) -- counted whether profiling is on or not.
  * `enabled`: 0 off, 1 every class, 2 only the colour sweeps (an event pair costs ~2.5 us of stream time: with all classes on,
  * a step of the headline workload records ~420 pairs = 1.1 ms; bench.py times its steps in mode 2).                       */
 int obia_set_profiling(obia_ctx *ctx, int enabled);

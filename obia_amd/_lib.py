@@ -175,7 +175,7 @@ class Context:
     def timing(self):
         lib = load()
         names = ["assign_ms", "sweeps", "features_ms", "connectivity_ms", "zonal_ms", "total_ms", "prepass_ms", "assign_px",
-                 "prepass_px", "assign_store_px", "assign_busy_ms", "prepass_busy_ms"]
+                 "prepass_px", "assign_store_px", "assign_busy_ms", "prepass_busy_ms", "batch_repeats"]
         return {n: lib.obia_last_timing(self._h, i) for i, n in enumerate(names)}
 
     def workspace_bytes(self):

@@ -57,6 +57,7 @@ struct Timing {
     double assign_px = 0, prepass_px = 0;   // pixels processed by the timed colour / pre-pass sweeps (sum over launches)
     double assign_store_px = 0;             // ... of the colour sweeps that also stored their labels (the last sweep of a batch)
     int sweeps = 0;
+    int batch_repeats = 0;                  // batches whose sweeps ran again with every sweep storing its labels (a valid pixel no window reached)
     // time during which at least one colour (pre-pass) sweep was running: equals assign_ms (prepass_ms) when the sweeps run one
     // after the other, less when groups of problems run side by side (slic_run_sweeps)
     double assign_busy_ms = 0, prepass_busy_ms = 0;

@@ -340,6 +340,7 @@ double obia_last_timing(obia_ctx *ctx, int what) {
         case 9: return ctx->timing.assign_store_px;
         case 10: return ctx->timing.assign_busy_ms;
         case 11: return ctx->timing.prepass_busy_ms;
+        case 12: return (double)ctx->timing.batch_repeats;
         default: return -1.0;
     }
 }

@@ -1664,6 +1664,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b, int mode) {
     }
     unsigned long long h[513];
     if (mode == 2) {   // the repeat of a batch whose deferred flag said "orphan": every sweep stores its labels
+        ctx->timing.batch_repeats += 1;
         fill_labels();
         OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * (size_t)b.total_cent * RQ, ctx->stream));
         OBIA_TRY(run_all(true));
@@ -1682,6 +1683,7 @@ int slic_run_sweeps(obia_ctx *ctx, SlicBatch &b, int mode) {
     OBIA_TRY(read_back(ctx, h, d_px, sizeof(h)));
     if (!store_all && (h[512] & 0xffffffffull) != 0ull) {
         // a pixel needed the label of an earlier sweep: repeat the batch from the seeds with every sweep storing its labels
+        ctx->timing.batch_repeats += 1;
         fill_labels();
         OBIA_HIP_TRY(hipMemsetAsync(b.d_acc, 0, sizeof(unsigned long long) * (size_t)b.total_cent * RQ, ctx->stream));
         OBIA_TRY(run_all(true));

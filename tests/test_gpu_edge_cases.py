@@ -251,3 +251,22 @@ def test_failed_tiled_call_leaves_nothing_running_and_the_context_reusable(monke
     ref, n_ref = create_tiled_segments(img, ctx=_lib.Context(0), **kw)
     del junk
     assert n == n_ref and torch.equal(lab, ref)
+
+
+def test_pixel_counters_of_a_call_after_a_fixed_point_call_on_the_same_context():
+    """Round 4: the orphan flag and pixel counters of a tiled batch travel to a pinned buffer of their own and are read after the
+    connectivity stage's synchronisation.  read_back() once freed that buffer when it grew its own (a 4104-byte read-back: the
+    exit_on_fixed_point path), and the next calls read recycled memory.  The counters of a plain call must not depend on what ran
+    before it on the context."""
+    from obia_amd import _lib
+    from obia_amd.tiling import create_tiled_segments
+    img = torch.as_tensor(synth(300, 320, 8, seed=31)).cuda()
+    ctx = _lib.Context(0)
+    ctx.set_profiling(1)
+    kw = dict(tile_size=128, buffer=16, crown_radius=3, pixel_size=(1.0, 1.0), ctx=ctx)
+    create_tiled_segments(img, **kw)
+    a = ctx.timing()
+    create_tiled_segments(img, exit_on_fixed_point=True, **kw)
+    create_tiled_segments(img, **kw)
+    b = ctx.timing()
+    assert a["assign_px"] == b["assign_px"] == a["prepass_px"] == b["prepass_px"] > 0

@@ -154,3 +154,29 @@ def test_tiler_with_a_corner_length_that_is_not_a_whole_number_of_pixels(oracle,
     ref, n_ref = tiler.create_tiled_segments(img, mask, **kw)
     lab, n = create_tiled_segments(torch.as_tensor(img).cuda(), input_mask=mask, **kw)
     assert n == n_ref and np.array_equal(lab.cpu().numpy(), ref)
+
+
+def test_tiler_batch_with_orphan_pixels_equals_the_oracle(oracle):
+    """A valid pixel that no window reaches keeps the label of the sweep before, which the tiler's sweeps do not store: the batch's
+    orphan flag -- read after the connectivity stage since round 4 (slic_run_sweeps mode 1, slic_sweeps_settle) -- makes the batch
+    run again with every sweep storing, and the connectivity stage with it.  Islands of a few valid pixels far from every seed
+    (farther than two grid steps) produce such pixels in black and in white tiles."""
+    from obia_amd.tiling import create_tiled_segments
+    from oracle import tiler
+    rs = np.random.RandomState(12)
+    H, W = 256, 300
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.stack([350 * np.sin(xx / (9 + 3 * c)) * np.cos(yy / (12 + 2 * c)) + 900 + 60 * c + rs.normal(0, 22, (H, W)) for c in range(4)], -1).astype(np.float32)
+    mask = np.zeros((H, W), bool)
+    mask[:, :70] = True                       # a block that gets the seeds ...
+    mask[10:250:40, 150:152] = True           # ... and islands 80 pixels away from it, two pixels wide
+    mask[30:250:40, 260:263] = True
+    kw = dict(tile_size=128, buffer=16, crown_radius=6.0, pixel_size=(1.0, 1.0), compactness=10.0)
+    from obia_amd import _lib
+    ctx = _lib.Context(0)
+    ref, n_ref = tiler.create_tiled_segments(img, mask, **kw)
+    lab, n = create_tiled_segments(torch.as_tensor(img).cuda(), input_mask=mask, ctx=ctx, **kw)
+    lab = lab.cpu().numpy()
+    assert ctx.timing()["batch_repeats"] >= 1, "the case is meant to take the repeat path"
+    assert n == n_ref and np.array_equal(lab, ref)
+    assert (lab[~mask] == 0).all()

@@ -108,5 +108,10 @@ def test_random_tiled_case_vs_oracle(oracle, seed):
     if mask is not None:
         assert (lab[~mask] == 0).all()
     if n:
+        # ids are 1..N.  Every id has pixels -- except in the one situation a label raster cannot hold ("white tile without
+        # neighbouring segments", tiling.py:261-262): a segment lying wholly inside a corner square of a white tile whose polygon no
+        # segment meets stays in the reference's table while the new segments are drawn over it; it keeps its id and has no pixel left
+        # (the oracle's raster, which `lab` equals pixel for pixel, shows the same).  Seen once in 170 random geometries (seed 65).
         ids = np.unique(lab[lab > 0])
-        assert ids[0] == 1 and ids[-1] == n and len(ids) == n
+        assert ids[0] >= 1 and ids[-1] <= n and len(ids) >= n - 4
+        assert np.array_equal(ids, np.unique(ref[ref > 0]))
