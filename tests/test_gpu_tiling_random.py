@@ -111,7 +111,8 @@ def test_random_tiled_case_vs_oracle(oracle, seed):
         # ids are 1..N.  Every id has pixels -- except in the one situation a label raster cannot hold ("white tile without
         # neighbouring segments", tiling.py:261-262): a segment lying wholly inside a corner square of a white tile whose polygon no
         # segment meets stays in the reference's table while the new segments are drawn over it; it keeps its id and has no pixel left
-        # (the oracle's raster, which `lab` equals pixel for pixel, shows the same).  Seen once in 170 random geometries (seed 65).
+        # (the oracle's raster, which `lab` equals pixel for pixel, shows the same).  Seen twice in 170 random geometries (seeds 65 and
+        # 125: pixel sizes of 0.3 make segments of a few pixels, a dozen of which fit into one corner square).
         ids = np.unique(lab[lab > 0])
-        assert ids[0] >= 1 and ids[-1] <= n and len(ids) >= n - 4
+        assert ids[0] >= 1 and ids[-1] <= n
         assert np.array_equal(ids, np.unique(ref[ref > 0]))
