@@ -59,7 +59,7 @@ __device__ __forceinline__ void unite(int *parent, int a, int b) {
 }
 
 // ---- tile-local union-find in LDS -------------------------------------------------------------------------------
-// A workgroup resolves the components of one 64x32 pixel tile entirely in LDS (labels + 16-bit local parents),
+// A workgroup resolves the components of one 64x32 pixel tile in LDS (16-bit local parents; the labels stay in registers),
 // then publishes parent[pixel] = GLOBAL index of the pixel's tile-local root.  Local indices are row-major inside
 // the tile, so "smaller local index" == "smaller global index": the local root is the first pixel of the tile's
 // part of the component, and linking larger roots under smaller ones across tiles (cc_seam_kernel) keeps the
@@ -96,10 +96,15 @@ __device__ __forceinline__ void lunite(unsigned short *par, int a, int b) {
     }
 }
 
+// Round 4: the labels stay in REGISTERS.  A wave owns eight consecutive rows of the tile (lane = column), so the pixel above is the
+// same lane's previous row, the pixel to the left one lane away (__shfl_up), and which contacts issue a union is decided on 64-bit
+// lane masks in scalar registers: no label array in LDS, no four LDS reads per pixel for the neighbour tests (the kernel is bound by
+// instruction issue: 8 pixels per lane, 20 KB of LDS per workgroup -> 12 KB).
 __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restrict__ probs, const int32_t *__restrict__ lab,
                                                       int *__restrict__ parent, int *__restrict__ size, int mask_label,
                                                       unsigned long long *__restrict__ lrbits) {
-    __shared__ int s_lab[CT_N];
+    constexpr int RPW = CT_H / 4;   // rows per wave
+    static_assert(CT_W == 64 && CT_H % 4 == 0, "a wave is one tile row wide");
     __shared__ unsigned short s_par[CT_N];
     __shared__ int s_cnt[CT_N];
     const CcProblem P = probs[blockIdx.y];
@@ -107,63 +112,67 @@ __global__ __launch_bounds__(256) void cc_tile_kernel(const CcProblem *__restric
     const int tile = blockIdx.x;
     if (tile >= tiles_x * ((P.H + CT_H - 1) / CT_H)) return;
     const int ty0 = (tile / tiles_x) * CT_H, tx0 = (tile % tiles_x) * CT_W;
-    const int tid = threadIdx.x;
-    // 1. labels -> LDS; parents start at the head of the horizontal run where that is one step away
-    for (int i = tid; i < CT_N; i += 256) {
-        const int ly = i / CT_W, lx = i % CT_W;
-        const int y = ty0 + ly, x = tx0 + lx;
-        s_lab[i] = (y < P.H && x < P.W) ? lab[P.pix_off + (long long)y * P.W + x] : mask_label;
-    }
-    __syncthreads();
-    // a wave holds one tile row (CT_W == 64): the parent of a pixel is the head of its horizontal run, found with one
-    // ballot (the highest run start at or below the lane), so the chains that lfind() walks only hop between run heads
-    int runlen[CT_N / 256];   // pixels of the horizontal run this lane heads (0: not a head, or masked)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = tx0 + lane, ly0 = wv * RPW;
+    const bool xin = x < P.W;
+    // 1. labels: rows ly0 - 1 .. ly0 + RPW - 1 (the row above the wave's first one is another wave's -- read again, a cache hit -- or,
+    // for the first wave, another tile's: that contact is cc_seam_kernel's)
+    int l[RPW + 1];
 #pragma unroll
-    for (int j = 0; j < CT_N / 256; ++j) {
-        const int i = tid + 256 * j;
-        const int lx = i % CT_W;
-        const int l = s_lab[i];
-        const bool start = (l == mask_label) || lx == 0 || s_lab[i - 1] != l;
+    for (int j = 0; j <= RPW; ++j) {
+        const int y = ty0 + ly0 + j - 1;
+        l[j] = (xin && y < P.H && (j > 0 || wv > 0)) ? lab[P.pix_off + (long long)y * P.W + x] : mask_label;
+    }
+    // the parent of a pixel is the head of its horizontal run, found with one ballot (the highest run start at or below the lane), so
+    // the chains that lfind() walks only hop between run heads
+    unsigned long long starts[RPW];
+    int runlen[RPW];                // pixels of the horizontal run this lane heads (0: not a head, or masked)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int i = (ly0 + j) * CT_W + lane;
+        const int lc = l[j + 1];
+        const int lft = __shfl_up(lc, 1);
+        const bool start = (lc == mask_label) || lane == 0 || lft != lc;
         const unsigned long long all = __ballot(start);
-        const unsigned long long below = all & (~0ull >> (63 - lx));
-        s_par[i] = (unsigned short)(i - lx + (63 - __clzll((long long)below)));
-        const unsigned long long above = lx < 63 ? (all >> (lx + 1)) : 0ull;      // run starts to the right of this lane
-        const int end = above ? lx + 1 + __builtin_ctzll(above) : CT_W;
-        runlen[j] = (start && l != mask_label) ? end - lx : 0;
+        starts[j] = all;
+        const unsigned long long below = all & (~0ull >> (63 - lane));
+        s_par[i] = (unsigned short)(i - lane + (63 - __clzll((long long)below)));
+        const unsigned long long above = lane < 63 ? (all >> (lane + 1)) : 0ull;      // run starts to the right of this lane
+        const int end = above ? lane + 1 + __builtin_ctzll(above) : CT_W;
+        runlen[j] = (start && lc != mask_label) ? end - lane : 0;
         s_cnt[i] = 0;
     }
     __syncthreads();
-    // 2. vertical contacts (only the first pixel of a horizontal contact issues the union)
-    for (int i = tid + CT_W; i < CT_N; i += 256) {
-        const int lx = i % CT_W;
-        const int l = s_lab[i];
-        if (l == mask_label || s_lab[i - CT_W] != l) continue;
-        const bool left_same = lx > 0 && s_lab[i - 1] == l && s_lab[i - CT_W - 1] == l;
-        if (!left_same) lunite(s_par, i, i - CT_W);
+    // 2. vertical contacts: only the first pixel of a horizontal contact issues the union -- a contact whose left neighbour has the
+    // same label in this row (no run start here) and a vertical contact of its own is covered by that neighbour's
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const bool vert = l[j + 1] != mask_label && l[j] == l[j + 1];
+        const unsigned long long vs = __ballot(vert);
+        const unsigned long long issue = vs & ~(~starts[j] & (vs << 1));
+        if ((issue >> lane) & 1ull) { const int i = (ly0 + j) * CT_W + lane; lunite(s_par, i, i - CT_W); }
     }
     __syncthreads();
     // 3. pixel count of every tile-local component at its local root (one LDS add per horizontal run), then publish the
-    // global index of the local root.  cc_flatten_kernel sums the local counts per global root: one global atomic per
-    // tile-local component instead of one per wave and root.
-    int rloc[CT_N / 256];
+    // global index of the local root
+    int rloc[RPW];
 #pragma unroll
-    for (int j = 0; j < CT_N / 256; ++j) {
-        const int i = tid + 256 * j;
-        rloc[j] = s_lab[i] != mask_label ? lfind(s_par, i) : -1;
+    for (int j = 0; j < RPW; ++j) {
+        const int i = (ly0 + j) * CT_W + lane;
+        rloc[j] = l[j + 1] != mask_label ? lfind(s_par, i) : -1;
         if (runlen[j] > 0) atomicAdd(&s_cnt[rloc[j]], runlen[j]);
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < CT_N / 256; ++j) {
-        const int i = tid + 256 * j;
-        const int ly = i / CT_W, lx = i % CT_W;
-        const int y = ty0 + ly, x = tx0 + lx;
-        if (y >= P.H || x >= P.W) continue;
+    for (int j = 0; j < RPW; ++j) {
+        const int i = (ly0 + j) * CT_W + lane;
+        const int y = ty0 + ly0 + j;
+        if (y >= P.H || !xin) continue;
         const long long g = P.pix_off + (long long)y * P.W + x;
         const int r = rloc[j];
         parent[g] = r >= 0 ? (int)(P.pix_off + (long long)(ty0 + r / CT_W) * P.W + tx0 + r % CT_W) : -1;
         // the pixel count of a tile-local component is written at its local root ONLY (a few words per tile instead of four bytes
-        // per pixel written here and read again by cc_flatten_kernel), and the local roots are flagged in a bitmap: size[] of any
+        // per pixel written here and read again by a flatten pass), and the local roots are flagged in a bitmap: size[] of any
         // other pixel is never read (round 4)
         if (r == i) {
             size[g] = s_cnt[i];
@@ -713,6 +722,120 @@ __global__ __launch_bounds__(64) void cc_small_bfs_kernel(const CcProblem *__res
     for (int j = 0; j < npush; ++j) work_out[base_slot + inc - npush + j] = s_push[threadIdx.x][j];
 }
 
+// ---- settle rounds on the pixels of the small components (round 4) ---------------------------------------------------------
+// Where small components are many (a noisy 3-band raster: one per 33 pixels, 6.5 M per step) the work-list rounds above spend their
+// time walking components one lane each -- up to two serial BFS walks per component and evaluation, with a queue and a visited map,
+// bound by the latency of their gathers.  But a settle time needs no walk:
+//     t(S) = min { p in S : p > m(S) },   m(S) = min over the neighbours N of S of t(N)
+// (t(N) = root of N for a surviving N; the formula covers the first attempt too: m(S) < first pixel of S  =>  t(S) = first pixel).
+// Both minima are order-free.  One dense pass lists the pixels of the small components (a tenth of the pixels in that regime),
+// grouped by component -- a component's pixels go to its slice of the BFS queue's layout (small_qoff) through a per-component
+// cursor -- with what never changes: the pixel and the codes of its four neighbours (-1: masked, outside, or the same component).
+// An evaluation is then two short loops over the component's slice (no queue, no visited map, nothing written but the time), and
+// the work list carries on as before: round 0 evaluates every small component, a later round the small neighbours of those whose
+// time moved.  Only the LAST step is order-dependent -- the reference keeps the last labelled neighbour its BFS meets -- and runs
+// once per component, from its final settle time (cc_small_target_kernel): one walk instead of one or two per evaluation.
+// (Tried on the way, `bench.py --bands 3`, connectivity per step: work list with walks 31.9 ms of small-component kernels; synchronous
+// rounds as two passes over ALL pixels 42 ms; over the list 17 ms + a list build that appended through ONE cursor, 48 ms:
+// profiles/r04_notes.md.)
+constexpr int T_NEVER = 0x7fffffff;
+// grid = (rows, problems)
+__global__ __launch_bounds__(256) void cc_small_pixels_kernel(const CcProblem *__restrict__ probs, const int *__restrict__ code,
+                                                              const int *__restrict__ small_qoff, int *__restrict__ ccur,
+                                                              int *__restrict__ px_g, int4 *__restrict__ px_cn, int cap) {
+    const CcProblem P = probs[blockIdx.y];
+    for (int y = blockIdx.x; y < P.H; y += gridDim.x) {
+        const long long row = P.pix_off + (long long)y * P.W;
+        for (int x = threadIdx.x; x < P.W; x += 256) {
+            const int c = code[row + x];
+            if (c > -2) continue;
+            int4 cn;
+            cn.x = x + 1 < P.W ? code[row + x + 1] : -1;
+            cn.y = x > 0 ? code[row + x - 1] : -1;
+            cn.z = y + 1 < P.H ? code[row + x + P.W] : -1;
+            cn.w = y > 0 ? code[row + x - P.W] : -1;
+            if (cn.x == c) cn.x = -1;
+            if (cn.y == c) cn.y = -1;
+            if (cn.z == c) cn.z = -1;
+            if (cn.w == c) cn.w = -1;
+            const int s = -c - 2;
+            const int idx = small_qoff[s] + atomicAdd(&ccur[s], 1);     // (ccur[s] ends as the component's pixel count)
+            if (idx < cap) { px_g[idx] = (int)(row + x); px_cn[idx] = cn; }
+        }
+    }
+}
+// one lane evaluates one small component; moved: its small neighbours join the next round's list (as in cc_small_bfs_kernel)
+__global__ __launch_bounds__(64) void cc_settle_eval_kernel(const int *__restrict__ small_qoff, const int *__restrict__ ccur,
+                                                            const int *__restrict__ px_g, const int4 *__restrict__ px_cn, int cap,
+                                                            int *__restrict__ settle, const int *__restrict__ work_in, int n_items,
+                                                            int *__restrict__ work_out, int *__restrict__ work_cnt,
+                                                            int *__restrict__ tag, int round) {
+    __shared__ int s_push[64][BFS_PUSH + 1];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int npush = 0;
+    if (i < n_items) {
+        const int s = work_in ? work_in[i] : i;
+        const int o = small_qoff[s];
+        int n = ccur[s];
+        if (o + n > cap) n = cap - o;
+        int m = T_NEVER;
+        for (int e = 0; e < n; ++e) {
+            const int4 cn = px_cn[o + e];
+            if ((cn.x & cn.y & cn.z & cn.w) == -1) continue;           // no foreign neighbour
+            const int a = cn.x >= 0 ? cn.x : (cn.x == -1 ? T_NEVER : ld_agent(&settle[-cn.x - 2]));
+            const int b = cn.y >= 0 ? cn.y : (cn.y == -1 ? T_NEVER : ld_agent(&settle[-cn.y - 2]));
+            const int c = cn.z >= 0 ? cn.z : (cn.z == -1 ? T_NEVER : ld_agent(&settle[-cn.z - 2]));
+            const int d = cn.w >= 0 ? cn.w : (cn.w == -1 ? T_NEVER : ld_agent(&settle[-cn.w - 2]));
+            m = min(m, min(min(a, b), min(c, d)));
+        }
+        int t = T_NEVER;
+        if (m != T_NEVER)
+            for (int e = 0; e < n; ++e) { const int g = px_g[o + e]; if (g > m && g < t) t = g; }
+        if (settle[s] != t) {
+            settle[s] = t;
+            for (int e = 0; e < n; ++e) {
+                const int4 cn = px_cn[o + e];
+                const int nb[4] = {cn.x, cn.y, cn.z, cn.w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (nb[d] > -2) continue;
+                    const int tt = -nb[d] - 2;
+                    if (atomicExch(&tag[tt], round + 1) != round + 1) {
+                        if (npush < BFS_PUSH) s_push[threadIdx.x][npush++] = tt;
+                        else work_out[atomicAdd(work_cnt, 1)] = tt;          // (more than BFS_PUSH new neighbours)
+                    }
+                }
+            }
+        }
+    }
+    // inclusive prefix of the lanes' counts, one atomic for the wave
+    int inc = npush;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if ((int)threadIdx.x >= off) inc += v; }
+    const int total = __shfl(inc, 63);
+    if (total == 0) return;
+    int base_slot = 0;
+    if (threadIdx.x == 63) base_slot = atomicAdd(work_cnt, total);
+    base_slot = __shfl(base_slot, 63);
+    for (int j = 0; j < npush; ++j) work_out[base_slot + inc - npush + j] = s_push[threadIdx.x][j];
+}
+// the one order-dependent step: the BFS of the reference from the component's settle time, for the last labelled neighbour it meets
+__global__ __launch_bounds__(64) void cc_small_target_kernel(const CcProblem *__restrict__ probs, int nprob, const int *__restrict__ code,
+                                                             const int *__restrict__ newlab, const int *__restrict__ small_list,
+                                                             const int *__restrict__ small_qoff, const int *__restrict__ settle,
+                                                             int *__restrict__ queue, int32_t *__restrict__ out, int *__restrict__ target, int n_small) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_small) return;
+    const int st = settle[s];
+    if (st == T_NEVER) { target[s] = -1; return; }
+    const CcProblem P = probs[find_prob(probs, nprob, small_list[s])];
+    int *q = queue + small_qoff[s];
+    int csize = 0, ms = 0;
+    const int adjacent = replay_bfs<true>(code, newlab, settle, -(s + 2), st, P.H, P.W, (int)P.pix_off, q, out, &csize, &ms, nullptr);
+    for (int i = 0; i < csize; ++i) out[q[i]] = 0;
+    target[s] = adjacent;
+}
+
 // from_above = 0: the optimistic start (every small component labelled at its first pixel); 1: the pessimistic one (never)
 __global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_small, int *__restrict__ settle, int from_above) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -835,7 +958,41 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         // value read lies between the start and the solution); never cut short: an unconverged round would write label 0.
         constexpr int ROUNDS_FROM_BELOW = 5;
         bool converged = false;
-        for (int side = (n_small > 8 * (long long)n_surv ? 1 : 0); side < 2 && !converged; ++side) {
+        // many small components and the reference's "written back as unset" rule in force (start_label 1): dense rounds for the times,
+        // one walk per component for its neighbour (see "dense settle rounds"); OBIA_CC_WORKLIST: developer switch, the work list
+        const bool dense = use_code && start_label == 1 && !std::getenv("OBIA_CC_WORKLIST");
+        if (dense) {
+            int *px_g = A.get<int>(small_px), *ccur = A.get<int>(n_small);
+            int4 *px_cn = A.get<int4>(small_px);
+            if (!px_g || !ccur || !px_cn) return OBIA_E_NOMEM;
+            int maxh = 1;
+            for (auto &P : probs) maxh = std::max(maxh, P.H);
+            OBIA_HIP_TRY(hipMemsetAsync(ccur, 0, sizeof(int) * (size_t)n_small, ctx->stream));
+            hipLaunchKernelGGL(cc_small_pixels_kernel, dim3(maxh, np), dim3(256), 0, ctx->stream, d_probs, code, small_qoff, ccur, px_g, px_cn, small_px);
+            for (int side = (n_small > 8 * (long long)n_surv ? 1 : 0); side < 2 && !converged; ++side) {
+                OBIA_HIP_TRY(hipMemsetAsync(tag, 0, sizeof(int) * (size_t)n_small, ctx->stream));
+                hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle, side);
+                int n_items = n_small;
+                const int *work_in = nullptr;
+                const long long max_rounds = side == 0 ? ROUNDS_FROM_BELOW : (long long)small_px + 2;
+                for (long long round = 0; round <= max_rounds; ++round) {
+                    if (std::getenv("OBIA_DEBUG_CC")) fprintf(stderr, "[obia cc]   (lists) side %d round %lld: %d items\n", side, round, n_items);
+                    OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
+                    hipLaunchKernelGGL(cc_settle_eval_kernel, dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, small_qoff, ccur, px_g, px_cn, small_px,
+                                       settle, work_in, n_items, work_a, counters + 5, tag, (int)(round & 0x3fffffff));
+                    int n_next = 0;
+                    OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
+                    if (n_next == 0) { converged = true; break; }
+                    work_in = work_a;
+                    std::swap(work_a, work_b);
+                    n_items = n_next;
+                }
+            }
+            if (converged)
+                hipLaunchKernelGGL(cc_small_target_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, code, newlab, small_list,
+                                   small_qoff, settle, queue, labels_out, target, n_small);
+        }
+        for (int side = (n_small > 8 * (long long)n_surv ? 1 : 0); !dense && side < 2 && !converged; ++side) {
             OBIA_HIP_TRY(hipMemsetAsync(tag, 0, sizeof(int) * (size_t)n_small, ctx->stream));
             hipLaunchKernelGGL(cc_settle_init_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, small_list, n_small, settle, side);
             int n_items = n_small;
