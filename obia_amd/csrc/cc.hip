@@ -764,48 +764,78 @@ __global__ __launch_bounds__(256) void cc_small_pixels_kernel(const CcProblem *_
         }
     }
 }
-// one lane evaluates one small component; moved: its small neighbours join the next round's list (as in cc_small_bfs_kernel)
+// one lane evaluates one small component; moved: its small neighbours join the next round's list (as in cc_small_bfs_kernel).
+// Components are 3.7 pixels on average with a tail up to min_size: among the 64 of a wave there is nearly always one of dozens of
+// pixels, and the wave would wait for that lane -- components above SETTLE_COOP pixels are left out of the per-lane part and
+// evaluated by the whole wave afterwards, 64 entries per step.
+constexpr int SETTLE_COOP = 12;
+__device__ __forceinline__ int settle_entry_min(const int4 cn, const int *__restrict__ settle) {
+    if ((cn.x & cn.y & cn.z & cn.w) == -1) return T_NEVER;           // no foreign neighbour
+    const int a = cn.x >= 0 ? cn.x : (cn.x == -1 ? T_NEVER : ld_agent(&settle[-cn.x - 2]));
+    const int b = cn.y >= 0 ? cn.y : (cn.y == -1 ? T_NEVER : ld_agent(&settle[-cn.y - 2]));
+    const int c = cn.z >= 0 ? cn.z : (cn.z == -1 ? T_NEVER : ld_agent(&settle[-cn.z - 2]));
+    const int d = cn.w >= 0 ? cn.w : (cn.w == -1 ? T_NEVER : ld_agent(&settle[-cn.w - 2]));
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
 __global__ __launch_bounds__(64) void cc_settle_eval_kernel(const int *__restrict__ small_qoff, const int *__restrict__ ccur,
                                                             const int *__restrict__ px_g, const int4 *__restrict__ px_cn, int cap,
                                                             int *__restrict__ settle, const int *__restrict__ work_in, int n_items,
                                                             int *__restrict__ work_out, int *__restrict__ work_cnt,
                                                             int *__restrict__ tag, int round) {
     __shared__ int s_push[64][BFS_PUSH + 1];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
     int npush = 0;
-    if (i < n_items) {
-        const int s = work_in ? work_in[i] : i;
-        const int o = small_qoff[s];
-        int n = ccur[s];
-        if (o + n > cap) n = cap - o;
-        int m = T_NEVER;
-        for (int e = 0; e < n; ++e) {
-            const int4 cn = px_cn[o + e];
-            if ((cn.x & cn.y & cn.z & cn.w) == -1) continue;           // no foreign neighbour
-            const int a = cn.x >= 0 ? cn.x : (cn.x == -1 ? T_NEVER : ld_agent(&settle[-cn.x - 2]));
-            const int b = cn.y >= 0 ? cn.y : (cn.y == -1 ? T_NEVER : ld_agent(&settle[-cn.y - 2]));
-            const int c = cn.z >= 0 ? cn.z : (cn.z == -1 ? T_NEVER : ld_agent(&settle[-cn.z - 2]));
-            const int d = cn.w >= 0 ? cn.w : (cn.w == -1 ? T_NEVER : ld_agent(&settle[-cn.w - 2]));
-            m = min(m, min(min(a, b), min(c, d)));
+    auto push_neighbours = [&](const int4 cn) {
+        const int nb[4] = {cn.x, cn.y, cn.z, cn.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (nb[d] > -2) continue;
+            const int tt = -nb[d] - 2;
+            if (atomicExch(&tag[tt], round + 1) != round + 1) {
+                if (npush < BFS_PUSH) s_push[lane][npush++] = tt;
+                else work_out[atomicAdd(work_cnt, 1)] = tt;          // (more than BFS_PUSH new neighbours)
+            }
         }
+    };
+    int s = 0, o = 0, n = 0;
+    if (i < n_items) {
+        s = work_in ? work_in[i] : i;
+        o = small_qoff[s];
+        n = ccur[s];
+        if (o + n > cap) n = cap - o;
+    }
+    if (n > 0 && n <= SETTLE_COOP) {
+        int m = T_NEVER;
+        for (int e = 0; e < n; ++e) m = min(m, settle_entry_min(px_cn[o + e], settle));
         int t = T_NEVER;
         if (m != T_NEVER)
             for (int e = 0; e < n; ++e) { const int g = px_g[o + e]; if (g > m && g < t) t = g; }
         if (settle[s] != t) {
             settle[s] = t;
-            for (int e = 0; e < n; ++e) {
-                const int4 cn = px_cn[o + e];
-                const int nb[4] = {cn.x, cn.y, cn.z, cn.w};
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (nb[d] > -2) continue;
-                    const int tt = -nb[d] - 2;
-                    if (atomicExch(&tag[tt], round + 1) != round + 1) {
-                        if (npush < BFS_PUSH) s_push[threadIdx.x][npush++] = tt;
-                        else work_out[atomicAdd(work_cnt, 1)] = tt;          // (more than BFS_PUSH new neighbours)
-                    }
-                }
-            }
+            for (int e = 0; e < n; ++e) push_neighbours(px_cn[o + e]);
+        }
+    }
+    unsigned long long coop = __ballot(n > SETTLE_COOP);
+    while (coop) {                                                   // (wave-uniform)
+        const int src = __builtin_ctzll(coop);
+        coop &= coop - 1;
+        const int sb = __shfl(s, src), ob = __shfl(o, src), nb = __shfl(n, src);
+        int m = T_NEVER;
+        for (int e = lane; e < nb; e += 64) m = min(m, settle_entry_min(px_cn[ob + e], settle));
+        m = wave_min_i32(m);
+        int t = T_NEVER;
+        if (m != T_NEVER)
+            for (int e = lane; e < nb; e += 64) { const int g = px_g[ob + e]; if (g > m && g < t) t = g; }
+        t = wave_min_i32(t);
+        const int old = settle[sb];
+        if (old != t) {
+            if (lane == 0) settle[sb] = t;
+            for (int e = lane; e < nb; e += 64) push_neighbours(px_cn[ob + e]);
         }
     }
     // inclusive prefix of the lanes' counts, one atomic for the wave
@@ -842,11 +872,23 @@ __global__ void cc_settle_init_kernel(const int *__restrict__ small_list, int n_
     if (s < n_small) settle[s] = from_above ? 0x7fffffff : small_list[s];
 }
 
-// final labels: survivors get rank + start_label; small components follow their adjacency chain
-__global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__ parent, const int *__restrict__ newlab,
-                                                         const int *__restrict__ target, long long n, int start_label,
-                                                         int mask_label, int max_hops, int32_t *__restrict__ out) {
-    const CcResolve R{parent, newlab, target, max_hops, start_label, mask_label};
+// the label a small component ends with: it follows its adjacency chain (a chain only leads to components that settled EARLIER: it
+// is acyclic and at most n_small long) to a surviving component's rank, or to nothing (-1)
+__global__ void cc_small_final_kernel(const int *__restrict__ parent, const int *__restrict__ newlab, const int *__restrict__ target,
+                                      int n_small, int max_hops, int *__restrict__ small_final) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_small) return;
+    int nl = -(s + 2), hops = 0;
+    while (nl < 0) {
+        const int t = target[-nl - 2];
+        if (t < 0 || ++hops > max_hops) { nl = -1; break; }
+        nl = newlab[parent[parent[t]]];
+    }
+    small_final[s] = nl;
+}
+
+// final labels: survivors get rank + start_label; small components the label their adjacency chain ends in
+__global__ __launch_bounds__(256) void cc_relabel_kernel(const CcResolve R, long long n, int32_t *__restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         out[i] = cc_resolve_label(R, i);
 }
@@ -933,11 +975,20 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     else
         hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
                            newlab, small_list, small_qoff, counters, rb);
+    int *settle_arr = nullptr;
     if (n_small > 0) {
-        int *settle = A.get<int>(n_small), *work_a = A.get<int>(n_small), *work_b = A.get<int>(n_small), *tag = A.get<int>(n_small);
+        int *settle = settle_arr = A.get<int>(n_small), *work_a = A.get<int>(n_small), *work_b = A.get<int>(n_small), *tag = A.get<int>(n_small);
         // the dense code[] pass pays when small components are many (one per 64 pixels or more: `bench.py --bands 3` has one per 33,
         // compactness 0.25 on eight bands one per ~170, where the pass cost 0.5 ms per step more than it saved)
-        const bool use_code = (long long)n_small * 64 >= n;
+        // (developer switch OBIA_CC_CODE_DIV: pixels per small component below which the dense code[] pass and the pixel lists are used)
+        static const long long code_div = std::getenv("OBIA_CC_CODE_DIV") ? atoll(std::getenv("OBIA_CC_CODE_DIV")) : 64;
+        const bool use_code = (long long)n_small * code_div >= n;
+        // the rounds' "moved" counters: a ring of words cleared once (a fill per round was a launch and a gap per round)
+        constexpr int RING = 64;
+        int *ring = A.get<int>(RING);
+        if (!ring) return OBIA_E_NOMEM;
+        OBIA_HIP_TRY(hipMemsetAsync(ring, 0, sizeof(int) * RING, ctx->stream));
+        long long ring_pos = 0;
         int *code = use_code ? A.get<int>(n) : parent;
         if (!settle || !work_a || !work_b || !tag || !code) return OBIA_E_NOMEM;
         OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
@@ -977,11 +1028,12 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
                 const long long max_rounds = side == 0 ? ROUNDS_FROM_BELOW : (long long)small_px + 2;
                 for (long long round = 0; round <= max_rounds; ++round) {
                     if (std::getenv("OBIA_DEBUG_CC")) fprintf(stderr, "[obia cc]   (lists) side %d round %lld: %d items\n", side, round, n_items);
-                    OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
+                    int *cnt = ring + (ring_pos++ % RING);
+                    if (ring_pos > RING && (ring_pos - 1) % RING == 0) OBIA_HIP_TRY(hipMemsetAsync(ring, 0, sizeof(int) * RING, ctx->stream));
                     hipLaunchKernelGGL(cc_settle_eval_kernel, dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, small_qoff, ccur, px_g, px_cn, small_px,
-                                       settle, work_in, n_items, work_a, counters + 5, tag, (int)(round & 0x3fffffff));
+                                       settle, work_in, n_items, work_a, cnt, tag, (int)(round & 0x3fffffff));
                     int n_next = 0;
-                    OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
+                    OBIA_TRY(read_back(ctx, &n_next, cnt, sizeof(int)));
                     if (n_next == 0) { converged = true; break; }
                     work_in = work_a;
                     std::swap(work_a, work_b);
@@ -1002,17 +1054,18 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
             const long long max_rounds = side == 0 ? ROUNDS_FROM_BELOW : (long long)small_px + 2;
             for (long long round = 0; round <= max_rounds; ++round) {
                 if (std::getenv("OBIA_DEBUG_CC")) fprintf(stderr, "[obia cc]   side %d round %lld: %d items\n", side, round, n_items);
-                OBIA_HIP_TRY(hipMemsetAsync(counters + 5, 0, sizeof(int), ctx->stream));
+                int *cnt = ring + (ring_pos++ % RING);
+                if (ring_pos > RING && (ring_pos - 1) % RING == 0) OBIA_HIP_TRY(hipMemsetAsync(ring, 0, sizeof(int) * RING, ctx->stream));
                 if (use_code)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(cc_small_bfs_kernel<true>), dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, code,
                                        newlab, small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
-                                       counters + 5, tag, (int)(round & 0x3fffffff));
+                                       cnt, tag, (int)(round & 0x3fffffff));
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(cc_small_bfs_kernel<false>), dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, code,
                                        newlab, small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
-                                       counters + 5, tag, (int)(round & 0x3fffffff));
+                                       cnt, tag, (int)(round & 0x3fffffff));
                 int n_next = 0;
-                OBIA_TRY(read_back(ctx, &n_next, counters + 5, sizeof(int)));
+                OBIA_TRY(read_back(ctx, &n_next, cnt, sizeof(int)));
                 if (n_next == 0) { converged = true; break; }
                 work_in = work_a;
                 std::swap(work_a, work_b);
@@ -1024,11 +1077,12 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
     if (std::getenv("OBIA_DEBUG_CC"))   // developer aid: the regime of this batch
         fprintf(stderr, "[obia cc] %lld px, %d problems: %d surviving, %d small components (%d px)\n", n, np, n_surv, n_small, small_px);
     debug_sync(ctx, "cc: rank apply + small components");
-    if (deferred)
-        *deferred = CcResolve{parent, newlab, target, n_small + 1, start_label, mask_label};
-    else
-        hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, target, n, start_label,
-                           mask_label, n_small + 1, labels_out);
+    // (`settle` is free again: it takes the components' final labels)
+    if (n_small > 0)
+        hipLaunchKernelGGL(cc_small_final_kernel, dim3(cdiv(n_small, 256)), dim3(256), 0, ctx->stream, parent, newlab, target, n_small, n_small + 1, settle_arr);
+    const CcResolve R{parent, newlab, settle_arr, start_label, mask_label};
+    if (deferred) *deferred = R;
+    else hipLaunchKernelGGL(cc_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, R, n, labels_out);
     OBIA_HIP_TRY(hipGetLastError());
     if (h_n_labels_out) *h_n_labels_out = n_surv;
     return OBIA_OK;

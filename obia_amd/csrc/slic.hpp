@@ -172,7 +172,7 @@ struct CcProblem { int H, W; long long pix_off; int min_size; int max_size; };  
 // somewhere else anyway (the tiler scatters them into the raster's id space) asks for this instead of the dense label map and
 // resolves each pixel where it consumes it (cc_resolve_label): one pass over the batch and 8 bytes per pixel less (round 4).
 // The arrays live in the context's arena: valid until the caller rewinds it.
-struct CcResolve { const int *parent; const int *newlab; const int *target; int max_hops; int start_label; int mask_label; };
+struct CcResolve { const int *parent; const int *newlab; const int *small_final; int start_label; int mask_label; };
 #if defined(__HIPCC__)
 __device__ __forceinline__ int cc_resolve_label(const CcResolve &R, long long i) {
     // (a pixel's parent is its tile-local root, whose parent is the root of the component: cc.hip, cc_roots_kernel)
@@ -180,13 +180,9 @@ __device__ __forceinline__ int cc_resolve_label(const CcResolve &R, long long i)
     if (p < 0) return R.mask_label;
     const int r = R.parent[p];
     int nl = R.newlab[r];
-    int hops = 0;
-    while (nl < 0) {   // a small component follows its adjacency chain
-        const int t = R.target[-nl - 2];
-        // a chain only leads to components that settled EARLIER: it is acyclic and at most n_small long
-        if (t < 0 || ++hops > R.max_hops) { nl = -1; break; }
-        nl = R.newlab[R.parent[R.parent[t]]];
-    }
+    // a small component took the label at the end of its adjacency chain: followed once per COMPONENT (cc_small_final_kernel), not
+    // per pixel -- a pixel of a small component costs one more gather, not four per hop (round 4)
+    if (nl < 0) nl = R.small_final[-nl - 2];
     return (nl >= 0) ? nl + R.start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
 }
 #endif
