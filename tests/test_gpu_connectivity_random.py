@@ -65,3 +65,27 @@ def test_random_connectivity_case_vs_oracle(oracle, seed):
     out = out.cpu().numpy()
     assert np.array_equal(out, ref), f"seed {seed}: {(out != ref).sum()} px differ (shape {lab.shape}, min_size {mn}, max_size {mx})"
     assert n == len(np.unique(ref[ref > 0]))
+
+
+@pytest.mark.parametrize("noise,min_size", [(4, 300), (3, 12)])
+def test_settle_times_from_pixel_lists_equal_the_work_list_walks(noise, min_size):
+    """Where small components are many the settle times come from per-component pixel lists (cc_settle_eval_kernel) and one walk
+    per component (cc_small_target_kernel); the work list of BFS walks (cc_small_bfs_kernel) stays for maps with few small
+    components and behind OBIA_CC_WORKLIST.  Same labels either way (the oracle comparison above runs on the default)."""
+    from obia_amd.segmentation import enforce_connectivity
+    rs = np.random.RandomState(77 + noise)
+    H, W = 1024, 1536
+    lab = rs.randint(1, noise + 1, (H, W)).astype(np.int32)
+    lab[300:310, :] = 0
+    lab[600:800, 200:900] = noise + 1
+    t = torch.as_tensor(lab).cuda()
+    old = os.environ.pop("OBIA_CC_WORKLIST", None)
+    try:
+        a, na = enforce_connectivity(t, min_size, H * W + 1, start_label=1)
+        os.environ["OBIA_CC_WORKLIST"] = "1"
+        b, nb = enforce_connectivity(t, min_size, H * W + 1, start_label=1)
+    finally:
+        os.environ.pop("OBIA_CC_WORKLIST", None)
+        if old is not None:
+            os.environ["OBIA_CC_WORKLIST"] = old
+    assert na == nb and torch.equal(a, b)

@@ -25,6 +25,7 @@ vals = {"VALUE": f"{b['value']:.0f}", "MS": f"{b['ms_per_step']:.1f}", "SW": f"{
         "C4IDEAL": (f"{c4ms / 8:.1f}" if c4ms else "n/a"), "C4BUDGET": (f"{c4ms / 6:.1f}" if c4ms else "n/a"),
         "B9": g(b9, "value"), "B9MS": g(b9, "ms_per_step", "{:.1f}"), "B9SW": g(b9, "sweep_avg_launch_ms", "{:.4f}"), "B9FR": g(b9, "sweep_roofline_frac", "{:.3f}"),
         "B3": g(b3, "value"), "B3MS": g(b3, "ms_per_step", "{:.1f}"), "QS": g(qs, "value"),
+        "B3X": (f"{b3['ms_per_step'] / b['ms_per_step']:.2f}" if b3 else "n/a"),
         "MOM": g(nr, "moments_ms", "{:.2f}"), "MOMGB": g(nr, "moments_GBps"), "TEX": g(nr, "texture_one_band_ms", "{:.1f}"),
         "CPU1": g(cpu, "value", "{:.2f}"), "CPU16": g(cpu.get("all_cores"), "value", "{:.1f}"), "CPULIB": g(cpu.get("library"), "value", "{:.2f}"),
         "IMPORT": (so.strip().splitlines()[0] if so.strip() else "n/a"),
