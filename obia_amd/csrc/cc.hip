@@ -976,6 +976,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         hipLaunchKernelGGL(cc_rank_apply_kernel, dim3(nb), dim3(SCAN_NT), 0, ctx->stream, d_probs, np, parent, size, n, block_sums,
                            newlab, small_list, small_qoff, counters, rb);
     int *settle_arr = nullptr;
+    int32_t *visited = nullptr;
     if (n_small > 0) {
         int *settle = settle_arr = A.get<int>(n_small), *work_a = A.get<int>(n_small), *work_b = A.get<int>(n_small), *tag = A.get<int>(n_small);
         // the dense code[] pass pays when small components are many (one per 64 pixels or more: `bench.py --bands 3` has one per 33,
@@ -991,7 +992,20 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
         long long ring_pos = 0;
         int *code = use_code ? A.get<int>(n) : parent;
         if (!settle || !work_a || !work_b || !tag || !code) return OBIA_E_NOMEM;
-        OBIA_HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(int32_t) * n, ctx->stream));
+        // the walks' visited map: all zero between calls (every walk clears its marks): no 4-byte-per-pixel fill per batch (round 4)
+        if ((size_t)n > ctx->cc_visited_px || ctx->cc_visited_dirty) {
+            if ((size_t)n > ctx->cc_visited_px) {
+                OBIA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (ctx->cc_visited) (void)hipFree(ctx->cc_visited);
+                ctx->cc_visited = nullptr; ctx->cc_visited_px = 0;
+                const size_t want = (size_t)n + (size_t)n / 8;
+                if (hipMalloc(&ctx->cc_visited, want * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); set_error("out of device memory (visited map of %zu pixels)", want); return OBIA_E_NOMEM; }
+                ctx->cc_visited_px = want;
+            }
+            OBIA_HIP_TRY(hipMemsetAsync(ctx->cc_visited, 0, sizeof(int32_t) * ctx->cc_visited_px, ctx->stream));
+        }
+        ctx->cc_visited_dirty = true;     // until this call has queued its last walk
+        visited = ctx->cc_visited;
         if (use_code) hipLaunchKernelGGL(cc_code_kernel, dim3(gs), dim3(256), 0, ctx->stream, parent, newlab, n, code);
         // The settle times solve  t(S) = first pixel of S after min over its neighbours N of t(N)  (t(N) = first pixel of N for a
         // surviving N; "never" when S has no later pixel).  A time is decided by strictly EARLIER times, so the system has exactly
@@ -1042,7 +1056,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
             }
             if (converged)
                 hipLaunchKernelGGL(cc_small_target_kernel, dim3(cdiv(n_small, 64)), dim3(64), 0, ctx->stream, d_probs, np, code, newlab, small_list,
-                                   small_qoff, settle, queue, labels_out, target, n_small);
+                                   small_qoff, settle, queue, visited, target, n_small);
         }
         for (int side = (n_small > 8 * (long long)n_surv ? 1 : 0); !dense && side < 2 && !converged; ++side) {
             OBIA_HIP_TRY(hipMemsetAsync(tag, 0, sizeof(int) * (size_t)n_small, ctx->stream));
@@ -1058,11 +1072,11 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
                 if (ring_pos > RING && (ring_pos - 1) % RING == 0) OBIA_HIP_TRY(hipMemsetAsync(ring, 0, sizeof(int) * RING, ctx->stream));
                 if (use_code)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(cc_small_bfs_kernel<true>), dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, code,
-                                       newlab, small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
+                                       newlab, small_list, small_qoff, start_label, settle, queue, visited, target, work_in, n_items, work_a,
                                        cnt, tag, (int)(round & 0x3fffffff));
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(cc_small_bfs_kernel<false>), dim3(cdiv(n_items, 64)), dim3(64), 0, ctx->stream, d_probs, np, code,
-                                       newlab, small_list, small_qoff, start_label, settle, queue, labels_out, target, work_in, n_items, work_a,
+                                       newlab, small_list, small_qoff, start_label, settle, queue, visited, target, work_in, n_items, work_a,
                                        cnt, tag, (int)(round & 0x3fffffff));
                 int n_next = 0;
                 OBIA_TRY(read_back(ctx, &n_next, cnt, sizeof(int)));
@@ -1073,6 +1087,7 @@ int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &prob
             }
         }
         if (!converged) { set_error("connectivity enforcement: settle rounds did not converge (%d small components)", n_small); return OBIA_E_INVALID; }
+        ctx->cc_visited_dirty = false;
     }
     if (std::getenv("OBIA_DEBUG_CC"))   // developer aid: the regime of this batch
         fprintf(stderr, "[obia cc] %lld px, %d problems: %d surviving, %d small components (%d px)\n", n, np, n_surv, n_small, small_px);

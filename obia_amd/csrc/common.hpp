@@ -74,6 +74,11 @@ struct obia_ctx {
     size_t pinned_bytes = 0;
     unsigned long long *defer_buf = nullptr;   // pinned landing area of a read-back that is looked at after a LATER synchronisation
     bool defer_pending = false;                // (slic_run_sweeps with defer: the orphan flag and pixel counters of the sweeps)
+    // visited map of the connectivity stage's component walks (cc.hip): every walk clears its own marks, so the map is all zero
+    // between calls and is cleared as a whole only when it grows or after a call that did not complete (cc_visited_dirty)
+    int32_t *cc_visited = nullptr;
+    size_t cc_visited_px = 0;
+    bool cc_visited_dirty = false;
     char *up_buf = nullptr;          // pinned ring for small host -> device tables (upload_async): no stream sync per upload
     size_t up_bytes = 0, up_used = 0;
     int profiling = 0;               // 0 off, 1 every span, 2 only the colour sweeps (obia_set_profiling)

@@ -281,6 +281,7 @@ void obia_destroy(obia_ctx *ctx) {
     if (ctx->up_buf) (void)hipHostFree(ctx->up_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->defer_buf) (void)hipHostFree(ctx->defer_buf);
+    if (ctx->cc_visited) (void)hipFree(ctx->cc_visited);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < obia_ctx::MAX_SIDE; ++i) {
         if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);

@@ -835,7 +835,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
     } else if (b.masked) {
         int *d_K = A.get<int>(np);
         if (!d_K) return OBIA_E_NOMEM;
-        OBIA_TRY(upload_async(ctx, b.d_probs, b.probs.data(), sizeof(SlicProblem) * np));
+        // (the descriptors slic_count_valid uploaded are still in place: the seeding reads H, W and pix_off only)
         hipLaunchKernelGGL(seed_masked_kernel, dim3(np), dim3(256), 0, ctx->stream, d_grids, b.d_probs, b.d_mask,
                            b.d_seed, b.d_cent_prob, d_K);
         OBIA_TRY(read_back(ctx, K.data(), d_K, sizeof(int) * np));

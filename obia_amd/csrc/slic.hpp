@@ -186,8 +186,9 @@ __device__ __forceinline__ int cc_resolve_label(const CcResolve &R, long long i)
     return (nl >= 0) ? nl + R.start_label : 0;   // `adjacent = 0` when no labelled neighbour exists
 }
 #endif
-// labels_out: the dense label map (always needed as scratch of the small-component replay).  deferred (nullable): when given, the
-// final relabel pass is NOT run -- labels_out holds no result -- and *deferred describes how to resolve a pixel.
+// labels_out: the dense label map.  deferred (nullable): when given, the final relabel pass is NOT run -- labels_out is not
+// written -- and *deferred describes how to resolve a pixel.  (The component walks mark their pixels in a map of the context's
+// that is all zero between calls, obia_ctx::cc_visited.)
 int enforce_connectivity_batch(obia_ctx *ctx, const std::vector<CcProblem> &probs, const int32_t *labels_in,
                                long long total_pix, int start_label, int32_t *labels_out, int *h_n_labels_out,
                                CcResolve *deferred = nullptr);
