@@ -65,7 +65,8 @@ int slic_single(obia_ctx *ctx, const float *img, int H, int W, int C, const uint
         b.d_fbox = A.get<float>((size_t)feat_boxes(H, W) * 2 * b.CP);
         if (!b.d_fbox) return OBIA_E_NOMEM;
     }
-    OBIA_TRY(slic_prepare_features(ctx, b, img, H, W, p->normalize_bands, to_lab, ratio));
+    b.prescale = slic_prescale(ratio, p->normalize_bands, to_lab, b.slic_zero);
+    OBIA_TRY(slic_prepare_features(ctx, b, img, H, W, p->normalize_bands, to_lab, ratio * b.prescale));
     std::vector<int> nseg(1, p->n_segments);
     OBIA_TRY(slic_plan_and_seed(ctx, b, nseg, nullptr, ext));
     if (b.probs[0].K <= 0) {

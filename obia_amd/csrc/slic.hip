@@ -577,6 +577,16 @@ int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *non
     return OBIA_OK;
 }
 
+float slic_prescale(float ratio, int normalize, int to_lab, bool slic_zero) {
+    if (!normalize || to_lab || slic_zero || !(ratio > 0.0f) || !(ratio < 3.0e38f)) return 1.0f;
+    if (const char *e = std::getenv("OBIA_NO_PRESCALE"); e && atoi(e) != 0) return 1.0f;   // developer switch (A/B timing; the labels are the same either way)
+    int e = 0;
+    (void)std::frexp((double)ratio, &e);   // the largest normalised feature is 1 * ratio: the rule of slic_features_finish
+    int s = 29 - e;
+    if (s > 40 || s < -24) return 1.0f;    // (the squared scale multiplies the spatial weight: stay far inside float32)
+    return (float)std::ldexp(1.0, s);
+}
+
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws, int normalize,
                           int to_lab, float ratio, std::vector<int> *skip) {
     (void)Hs;
@@ -859,7 +869,7 @@ int slic_plan_and_seed(obia_ctx *ctx, SlicBatch &b, const std::vector<int> &n_se
         P.ncy = cdiv(P.H, P.sy);
         P.ncx = cdiv(P.W, P.sx);
         const float stepf = (float)stepmax[p];
-        P.spatial_w = (float)(1.0 / ((double)stepf * (double)stepf));
+        P.spatial_w = (float)(1.0 / ((double)stepf * (double)stepf)) * (b.prescale * b.prescale);   // (a power of two: exact)
         P.sp_y = (float)b.spacing[1]; P.sp_x = (float)b.spacing[2];   // np.ascontiguousarray(spacing, dtype=image dtype)
         P.direct = (P.sp_y != 1.0f || P.sp_x != 1.0f) ? 1 : 0;
         P.m4_off = (int)m4_total;

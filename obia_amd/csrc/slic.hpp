@@ -109,6 +109,7 @@ struct SlicBatch {
     int *d_tl_req = nullptr;           // [total_tiles_all] last sweep in which a centroid that left its margin asked the tile to rebuild (-1: none)
     float *d_ref = nullptr;            // [total_cent][2] position a centroid's margin is measured from
     double fscale = 1.0;
+    float prescale = 1.0f;             // power of two already folded into the feature planes, the spatial weight and the centroid colours (slic_prescale); fscale is what is left
     bool exit_on_fixed_point = false;
     bool slic_zero = false;            // SLIC-zero: colour term scaled by the cluster's largest colour distance so far
 };
@@ -141,6 +142,13 @@ int slic_features_finish(SlicBatch &b, const unsigned *keys, const unsigned *non
                          std::vector<int> *skip);
 int slic_prepare_features(obia_ctx *ctx, SlicBatch &b, const float *src, int Hs, int Ws,
                           int normalize, int to_lab, float ratio, std::vector<int> *skip = nullptr);
+// The part of the fixed-point scale of the colour sums that is known BEFORE the features are computed -- normalised bands times
+// `ratio` reach exactly `ratio` -- as a power of two.  The caller multiplies it into the ratio it hands to the feature pass (exact: the
+// planes hold the reference's features times 2^s) and stores it in SlicBatch::prescale; slic_plan_and_seed scales the spatial weight
+// by its square, the centroid colours follow from the sums: every distance is the reference's times 2^(2s), every comparison and
+// every tie the same, and the sweeps convert a feature to fixed point by truncation alone (SlicBatch::fscale, taken from the largest
+// |feature| as before, comes out as 1).  1 when the range is not known beforehand (no normalisation, Lab) or SLIC-zero is on.
+float slic_prescale(float ratio, int normalize, int to_lab, bool slic_zero);
 // Does a batch with this image ratio (1 / compactness; to_lab: the features are Lab, ~100 units wide) use the colour-box bound?  (OBIA_COLOUR_BOUND=0/1 overrides.)
 bool slic_use_colour_bound(float ratio, bool to_lab = false);
 

@@ -33,6 +33,8 @@
 // A tile that meets more candidates than fit in LDS (tiny S, clustered centroids) takes slow_tile(), which
 // reads the bins directly; correctness never depends on the LDS capacity.
 #include "slic.hpp"
+
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -1132,23 +1134,34 @@ __device__ __forceinline__ void slic_assign_body(
                 }
                 ++nruns;
             };
+            // PRE: the feature planes already carry the fixed-point scale (slic_prescale: a power of two folded into the planes, the
+            // spatial weight and the centroid colours -- every distance is the reference's times that power, every comparison the
+            // same), so the conversion is the truncation alone: 32 multiplications per lane and footprint less (round 4)
+            auto merge_strip = [&](auto pre_tag) {
+                constexpr bool PRE = decltype(pre_tag)::value;
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                if (pk[j] != rkey) {
-                    close_run();
-                    rkey = pk[j]; pw = 0;
+                for (int j = 0; j < PPT; ++j) {
+                    if (pk[j] != rkey) {
+                        close_run();
+                        rkey = pk[j]; pw = 0;
 #pragma unroll
-                    for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
-                }
-                if (pk[j] >= 0) {
-                    pw += 1u | ((unsigned)(yb_i + j - ty0) << 8) | (xrel << 20);
-                    if (!LEAN && accum_color) {
+                        for (int ch = 0; ch < (LEAN ? 1 : CP); ++ch) rf[ch] = 0;
+                    }
+                    if (pk[j] >= 0) {
+                        pw += 1u | ((unsigned)(yb_i + j - ty0) << 8) | (xrel << 20);
+                        if (!LEAN && accum_color) {
 #pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch) rf[LEAN ? 0 : ch] += to_fixed32((j & 1) ? f2[LEAN ? 0 : ch][j >> 1].y : f2[LEAN ? 0 : ch][j >> 1].x, fs);   // (padded channels stay 0)
+                            for (int ch = 0; ch < NCH; ++ch) {   // (padded channels stay 0)
+                                const float fv = (j & 1) ? f2[LEAN ? 0 : ch][j >> 1].y : f2[LEAN ? 0 : ch][j >> 1].x;
+                                rf[LEAN ? 0 : ch] += PRE ? (int)fv : to_fixed32(fv, fs);
+                            }
+                        }
                     }
                 }
-            }
-            close_run();
+                close_run();
+            };
+            if (fs == 1.0f) merge_strip(std::true_type{});   // (kernel argument: a scalar branch)
+            else merge_strip(std::false_type{});
         }
         }
         STAMP(5)   // run merge

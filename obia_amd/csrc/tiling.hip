@@ -382,6 +382,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
     b.max_iter = S.sp.max_num_iter;
     b.exit_on_fixed_point = S.sp.exit_on_fixed_point != 0;
     b.slic_zero = S.sp.slic_zero != 0;
+    b.prescale = slic_prescale((float)(1.0 / S.sp.compactness), 1, (S.C == 3 && S.sp.convert2lab != 0) ? 1 : 0, b.slic_zero);   // (the prefetched planes carry the same factor)
     for (int i = 0; i < 3; ++i) { b.sigma[i] = S.sp.sigma_zyx[i]; b.spacing[i] = S.sp.spacing_zyx[i]; }
     const bool direct = (float)b.spacing[1] != 1.0f || (float)b.spacing[2] != 1.0f;   // anisotropic spacing: the direct sweep path
     if (direct) b.exit_on_fixed_point = false;
@@ -465,7 +466,7 @@ static int run_tile_batch(obia_ctx *ctx, TileState &S, std::vector<TileWin> &win
         OBIA_TRY(slic_features_finish(b, h + S.pf.cursor * (size_t)S.C * 2, h + nkeys + S.pf.cursor, h + nkeys + NP + S.pf.cursor, 1, &skip));
         S.pf.cursor += np;
     } else {
-        OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp.compactness), &skip));
+        OBIA_TRY(slic_prepare_features(ctx, b, S.img, S.H, S.W, 1, to_lab, (float)(1.0 / S.sp.compactness) * b.prescale, &skip));
     }
     std::vector<int> nvalid;
     debug_sync(ctx, "tiler: mask + features");
@@ -750,14 +751,14 @@ static int prefetch_white_launch(obia_ctx *ctx, TileState &S, bool beside) {
         OBIA_HIP_TRY(hipEventRecord(ctx->aux_fork, ctx->stream));
         OBIA_HIP_TRY(hipStreamWaitEvent(side, ctx->aux_fork, 0));
         OBIA_TRY(slic_features_launch(side, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
-                                      (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys, true, pf.d_fbox));
+                                      (float)(1.0 / S.sp.compactness) * slic_prescale((float)(1.0 / S.sp.compactness), 1, to_lab, S.sp.slic_zero != 0), pf.d_feat, pf.d_keys, true, pf.d_fbox));
         OBIA_HIP_TRY(hipEventRecord(ctx->aux_join, side));
         pf.on_side = true;
         return OBIA_OK;
     }
     ScopedSpan span(ctx, T_FEAT);
     OBIA_TRY(slic_features_launch(ctx->stream, S.C, CP, (int)NP, pf.d_windows, pf.maxh, S.img, S.W, 1, to_lab,
-                                  (float)(1.0 / S.sp.compactness), pf.d_feat, pf.d_keys, true, pf.d_fbox));
+                                  (float)(1.0 / S.sp.compactness) * slic_prescale((float)(1.0 / S.sp.compactness), 1, to_lab, S.sp.slic_zero != 0), pf.d_feat, pf.d_keys, true, pf.d_fbox));
     return OBIA_OK;
 }
 
