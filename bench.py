@@ -545,8 +545,8 @@ def main():
             # round-4 counters say stands in the way -- SQ_ACTIVE_INST_VALU 12.1 k cycles per wave x 6 waves per SIMD against
             # SQ_WAVE_CYCLES 73.6 k: the vector ALUs are 98 % busy in steady state (profiles/r04_notes.md, r04_pmc_sweep_kernels.txt);
             # with no feature / mask traffic at all the launch is 8 % shorter (OBIA_ABL_NOLOAD).  Dated figures, not live ones.
-            "roofline": {"bound": "hbm", "limited_by": "valu", "valu_busy_steady_state": 0.98,
-                         "limited_by_source": "profiles/r04_notes.md section 2 (PMC passes at 8192^2, round 4)",
+            "roofline": {"bound": "hbm", "limited_by": "valu", "valu_busy_steady_state": 0.91,
+                         "limited_by_source": "profiles/r04_pmc_sweep_kernels.txt (PMC passes at 8192^2 at the round's HEAD: 10.97 k vector-ALU cycles per wave x 6 waves per SIMD of 72.2 k cycles of wave life; 0.98 before the round's last two cuts of vector work, profiles/r04_notes.md sections 2, 11, 12)",
                          "kernel": f"slic_assign_kernel<{(C + 3) // 4 * 4},true,false,false,false,{C}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
